@@ -1,0 +1,168 @@
+/*
+ * naf_hip.h -- C ABI of libnaf_hip.so, the MI355X (gfx950) native NAF hot path.
+ *
+ * This is the drop-in boundary for the reference's native operator module `_hash_encoder`
+ * (reference: src/encoder/hashencoder/src/bindings.cpp:5-8, hashencoder.h:13-14) plus the fused
+ * field / ray-march / optimiser entry points that replace the ATen kernels behind
+ * src/render/render.py:82-212, src/network/network.py:34-58 and src/trainer.py:54-58,134-142.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - the caller allocates everything, the callee writes in place (reference ownership model,
+ *     hashgrid.py:30-35,59-64); "(+=)" marks buffers the callee accumulates into (caller zeroes them);
+ *   - `stream` is a hipStream_t passed as void* (NULL = legacy default stream, which is what the
+ *     reference uses, hashencoder.cu:306,336);
+ *   - every function returns NAF_OK (0) or a negative naf_status; naf_last_error() returns a
+ *     thread-local human readable message for the last failure on the calling thread;
+ *   - launches are asynchronous; no function synchronises or allocates device memory.
+ */
+#ifndef NAF_HIP_H
+#define NAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum naf_status {
+    NAF_OK = 0,
+    NAF_ERR_INVALID_ARGUMENT = -1, /* null pointer, zero size, misaligned pointer ...            */
+    NAF_ERR_UNSUPPORTED = -2,      /* reference: std::runtime_error("GridEncoding: C must be 1, 2, 4, or 8.") hashencoder.cu:310,324 */
+    NAF_ERR_LAUNCH = -3            /* hipGetLastError() != hipSuccess after the launch            */
+} naf_status;
+
+/* storage type of tables / features; arithmetic is always fp32 (hashencoder.cu:107-143) */
+typedef enum naf_dtype { NAF_F32 = 0, NAF_F16 = 1, NAF_BF16 = 2 } naf_dtype;
+
+/* layout of per-point feature tensors */
+typedef enum naf_layout {
+    NAF_LAYOUT_LBC = 0, /* [L, B, C]  level-major, what kernel_grid writes (hashencoder.cu:95)        */
+    NAF_LAYOUT_BLC = 1  /* [B, L*C]   what _hash_encode.forward returns after permute (hashgrid.py:40) */
+} naf_layout;
+
+const char *naf_last_error(void);
+int naf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * E6  hash_encode_forward   (replaces hashencoder.cu:373-396 / hashencoder.h:13)
+ *   inputs      f32  [B, D]   in [0,1]
+ *   embeddings  dtype [sum_l T_l, C]
+ *   offsets     i32  [L+1]    (device)
+ *   outputs     dtype, layout `out_layout`
+ *   dy_dx       dtype [B, L, D, C]  written iff calc_grad_inputs != 0 (may be NULL otherwise)
+ * D in {2,3}, C in {1,2,4,8} else NAF_ERR_UNSUPPORTED.
+ */
+int naf_hash_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H, int calc_grad_inputs,
+                            void *dy_dx, int dtype, int out_layout, void *stream);
+
+/* E7/E8  hash_encode_backward  (replaces hashencoder.cu:398-428 / hashencoder.h:14)
+ *   grad             dtype, layout `grad_layout`
+ *   grad_embeddings  f32 [sum_l T_l, C]  (+=)   -- always fp32 (the reference accumulates in scalar_t)
+ *   grad_inputs      f32 [B, D]          (+=)   iff calc_grad_inputs != 0
+ */
+int naf_hash_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
+                             float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H,
+                             int calc_grad_inputs, const void *dy_dx, float *grad_inputs, int dtype, int grad_layout,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R2  stratified sampling along rays  (replaces the ATen ops of render.py:87-105)
+ *   rays    f32 [n_rays, 8]  = origin(3) direction(3) near far   (tigre.py:248-255)
+ *   t_rand  f32 [n_rays, S]  jitter in [0,1) or NULL; with NULL and perturb != 0 the jitter is the
+ *           counter-based generator naf_jitter(seed, ray, sample) documented in DESIGN.md
+ *   z_vals  f32 [n_rays, S]  out
+ *   pts     f32 [n_rays, S, 3] out, clamped to +-(bound - 1e-6)
+ */
+int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float *pts, uint32_t n_rays,
+                    uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,
+                    void *stream);
+
+/* R4  line integral acc = sum_s sigma_s * dist_s  (render.py:192-201), and its backward.
+ *   sigma f32 [n_rays, S]; z_vals f32 [n_rays, S]; rays f32 [n_rays, 8]; acc f32 [n_rays]
+ *   backward: grad_sigma[r,s] = grad_acc[r] * dist[r,s]
+ */
+int naf_integrate_forward(const float *sigma, const float *z_vals, const float *rays, float *acc, uint32_t n_rays,
+                          uint32_t n_samples, void *stream);
+int naf_integrate_backward(const float *grad_acc, const float *z_vals, const float *rays, float *grad_sigma,
+                           uint32_t n_rays, uint32_t n_samples, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused field + ray march for the canonical NAF network (network.py:6-58 with num_layers=4,
+ * hidden_dim=32, skips=[2], out_dim=1, in_dim = L*C = 32; config/NAME.yaml:7-19).
+ *
+ * MLP parameter block `mlp` (f32, 4225 values, row-major like nn.Linear.weight):
+ *   W0[32][32] b0[32] W1[32][32] b1[32] W2[32][64] b2[32] W3[1][32] b3[1]
+ * `grad_mlp` (+=) has the same layout.
+ */
+#define NAF_MLP_PARAMS 4225
+
+typedef struct naf_render_cfg {
+    uint32_t n_samples;      /* S (render.py:87)                                                  */
+    int32_t perturb;         /* stratified jitter on/off (render.py:94-100)                       */
+    float bound;             /* network bound (render.py:103, hashgrid.py:125)                    */
+    uint32_t L, C, H;        /* encoder levels / level_dim / base_resolution (hashgrid.py:78-86)  */
+    int32_t table_dtype;     /* naf_dtype of `embeddings`                                         */
+    int32_t mlp_precision;   /* NAF_F32: exact fp32 MFMA (parity mode); NAF_BF16: bf16 MFMA, fp32 accumulate */
+    int32_t last_activation; /* 0 sigmoid, 1 leaky-relu, 2 tanh, 3 none (network.py:23-32)        */
+    uint64_t seed;           /* jitter seed when t_rand == NULL                                   */
+    uint32_t ray_index_base; /* global index of ray 0 of this call (jitter stream is per global ray) */
+    uint32_t reserved;
+} naf_render_cfg;
+
+/* Workspace size in bytes for naf_render_* / naf_field_forward over `n_points` points (= n_rays * n_samples for the
+ * render entry points): feature and feature-gradient tensors [L, n_points, C] plus the MLP-gradient slabs. */
+size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points);
+
+/* Forward only (eval, train.py:235-239): acc[r] = sum_s sigma(pts[r,s]) * dist[r,s]. */
+int naf_render_forward(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
+                       const float *mlp, float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
+                       void *stream);
+
+/* Backward of naf_render_forward for an arbitrary upstream gradient grad_acc[r] = dLoss/dacc[r]
+ * (what autograd hands to the renderer): grad_embeddings (+=), grad_mlp (+=).
+ * features_valid != 0 promises that `workspace` still holds the features naf_render_forward wrote for the SAME
+ * rays / t_rand / parameters; with 0 they are recomputed first.
+ */
+int naf_render_backward(const float *rays, const float *t_rand, const float *grad_acc, const void *embeddings,
+                        const int32_t *offsets, const float *mlp, float *grad_embeddings, float *grad_mlp, uint32_t n_rays,
+                        const naf_render_cfg *cfg, void *workspace, int features_valid, void *stream);
+
+/* Training step body (train.py:69-127 + trainer.py:134-142 minus the optimiser):
+ *   acc = render(rays); loss = sum_r weight[r] * (acc[r] - target[r])^2  with weight[r] = mask/len
+ *   (the caller encodes the reference's masked chunk means in `ray_weight`);
+ *   grad_embeddings (+=), grad_mlp (+=), loss_out[0] (+=).
+ */
+int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                     const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                     float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                     const naf_render_cfg *cfg, void *workspace, void *stream);
+
+/* Field query sigma(x) for a point list (volume query, train.py:246-250): pts f32 [B,3] in [-bound,bound]. */
+int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,
+                      float *sigma, uint32_t B, const naf_render_cfg *cfg, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * T4  Adam (torch.optim.Adam semantics, trainer.py:54: lr, betas=(0.9,0.999), eps=1e-8, no weight decay,
+ * amsgrad off).  `step` is the 1-based step count.  If param_lp != NULL a low-precision copy of the
+ * updated parameters (naf_dtype lp_dtype) is written too (16-bit tables keep an fp32 master).
+ * If zero_grad != 0 the gradient buffer is cleared in the same pass.
+ */
+int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype,
+                  uint64_t n, float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale,
+                  int zero_grad, void *stream);
+
+/* E2  encoder input stage (hashgrid.py:122-125) without host round trips:
+ *   out01[i] = (x[i] + size) / (2*size)   (IEEE fp32 add and divide, as torch evaluates it on the host)
+ *   flag[0] |= 1 if any x[i] < -size or x[i] > size (or NaN); flag[1], flag[2] = min / max of x as
+ *   order-preserving int32 (caller initialises flag to {0, INT32_MAX, INT32_MIN}).
+ * out01 may be NULL (range check only).
+ */
+int naf_normalize_inputs(const float *x, uint64_t n, float size, float *out01, int32_t *flag, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAF_HIP_H */

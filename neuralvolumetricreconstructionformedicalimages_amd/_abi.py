@@ -1,0 +1,100 @@
+"""ctypes binding of libnaf_hip.so (C ABI: include/naf_hip.h).
+
+Replaces the pybind11 module `_hash_encoder` of the reference (src/encoder/hashencoder/src/bindings.cpp:5-8,
+loaded by backend.py:6-16).  There is deliberately NO fallback: if the library is missing or a call fails the
+caller gets a RuntimeError -- the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+F32, F16, BF16 = 0, 1, 2
+LAYOUT_LBC, LAYOUT_BLC = 0, 1
+MLP_PARAMS = 4225
+
+_DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+_lib = None
+
+
+class RenderCfg(ctypes.Structure):
+    """struct naf_render_cfg (include/naf_hip.h)."""
+    _fields_ = [
+        ("n_samples", ctypes.c_uint32), ("perturb", ctypes.c_int32), ("bound", ctypes.c_float),
+        ("L", ctypes.c_uint32), ("C", ctypes.c_uint32), ("H", ctypes.c_uint32),
+        ("table_dtype", ctypes.c_int32), ("mlp_precision", ctypes.c_int32), ("last_activation", ctypes.c_int32),
+        ("seed", ctypes.c_uint64), ("ray_index_base", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/naf_hip.h one to one (checked by tests/test_abi_symbols.py)
+_vp, _u32, _u64, _i32, _f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float
+SIGNATURES = {
+    "naf_last_error": (ctypes.c_char_p, []),
+    "naf_abi_version": (_i32, []),
+    "naf_hash_encode_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _i32, _i32, _vp]),
+    "naf_hash_encode_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "naf_sample_rays": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _f32, _u64, _u32, _vp]),
+    "naf_integrate_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "naf_integrate_backward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "naf_render_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
+    "naf_render_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_render_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _i32, _vp]),
+    "naf_render_train": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _u64, _f32, _f32, _f32, _f32, _u32, _f32, _i32, _vp]),
+    "naf_normalize_inputs": (_i32, [_vp, _u64, _f32, _vp, _vp, _vp]),
+}
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load (once) the prebuilt in-tree library; raise loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the NAF hot path.")
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().naf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libnaf_hip {what} failed ({rc}): {msg}")
+
+
+def dtype_code(dt):
+    try:
+        return _DTYPE_CODE[dt]
+    except KeyError:
+        raise RuntimeError(f"libnaf_hip: unsupported dtype {dt}") from None
+
+
+def ptr(t):
+    """Device pointer of a tensor that must already live on the GPU and be contiguous (hashencoder.cu:17-18)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libnaf_hip: tensor must be a CUDA/HIP tensor (no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError("libnaf_hip: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

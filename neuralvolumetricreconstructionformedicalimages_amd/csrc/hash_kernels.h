@@ -1,0 +1,175 @@
+// hash_kernels.h -- templated gfx950 kernels of the multi-resolution hash-grid encoder.
+//
+// Shared by hash_encode.hip (stand-alone operator, reference ABI) and render_fused.hip (points generated on the
+// fly from rays).  Follows reference src/encoder/hashencoder/src/hashencoder.cu:
+//   forward  kernel_grid           :77-198      backward  kernel_grid_backward :201-272
+//
+// MI355X design notes
+//   * one lane = one (point, level); a wave covers 64 consecutive points, so consecutive samples of a ray sit in
+//     neighbouring lanes and share cache lines on the coarse levels;
+//   * level-major grid (blockIdx.y = level): at any moment an XCD works on one level, whose slice (<= 4 MB fp32 /
+//     2 MB 16-bit at T=2^19) is what its 4 MB L2 has to hold;
+//   * the level regime (dense / wrapped-dense / hash, mask vs modulo) is decoded once per wave on the scalar unit;
+//   * C-wide table rows are fetched with one 4/8/16-byte load; all 2^D gathers of a lane are issued back to back
+//     before the first use, so every lane keeps 2^D independent misses in flight;
+//   * [L,B,C] features are written as fully coalesced C*sizeof(T)*64-byte rows per wave.
+#pragma once
+
+#include "naf_device.h"
+
+namespace naf {
+
+// ---- where the points come from -----------------------------------------------------------------------
+// (a) caller-supplied coordinates already in [0,1]  (reference kernel contract, hashencoder.cu:383)
+template <uint32_t D>
+struct SrcUnit {
+    const float *__restrict__ x;
+    __device__ __forceinline__ void get(uint32_t b, float (&out)[D]) const {
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) out[d] = x[(size_t)b * D + d];
+    }
+};
+
+// (b) raw coordinates in [-bound, bound]: the (x+size)/(2 size) of hashgrid.py:125 is applied in registers
+struct SrcRaw {
+    const float *__restrict__ pts;
+    float bound;
+    __device__ __forceinline__ void get(uint32_t b, float (&out)[3]) const {
+        const float denom = 2.0f * bound;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) out[d] = (pts[(size_t)b * 3 + d] + bound) / denom;
+    }
+};
+
+// (c) sample s of ray r (b = r*S + s): stratified depth, point on ray, clamp, normalise
+//     (render.py:87-105 + hashgrid.py:125) -- nothing [B,3]-sized ever touches HBM.
+struct SrcRays {
+    const float *__restrict__ rays;    // [n_rays, 8]
+    const float *__restrict__ t_rand;  // [n_rays, S] or nullptr
+    uint32_t S;
+    bool perturb;
+    float bound;
+    uint64_t seed;
+    uint32_t ray_base;
+    __device__ __forceinline__ float depth(uint32_t r, uint32_t s, float near, float far) const {
+        float u = 0.0f;
+        if (perturb) u = t_rand ? t_rand[(size_t)r * S + s] : jitter(seed, ray_base + r, s);
+        return sample_z(near, far, s, S, perturb, u);
+    }
+    __device__ __forceinline__ void get(uint32_t b, float (&out)[3]) const {
+        const uint32_t r = b / S, s = b - r * S;
+        const float *ray = rays + (size_t)r * 8;
+        const float z = depth(r, s, ray[6], ray[7]);
+        const float lim = bound - 1e-6f, denom = 2.0f * bound;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) {
+            float p = ray[d] + ray[3 + d] * z;
+            p = fminf(fmaxf(p, -lim), lim);
+            out[d] = (p + bound) / denom;
+        }
+    }
+};
+
+// ---- forward ------------------------------------------------------------------------------------------
+template <typename T, uint32_t D, uint32_t C, typename Src>
+__global__ void __launch_bounds__(256)
+hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
+                    typename T::store_t *__restrict__ outputs, uint32_t B, uint32_t L, uint32_t H, bool blc_layout,
+                    typename T::store_t *__restrict__ dy_dx) {
+    using S = typename T::store_t;
+    const uint32_t level = blockIdx.y;
+    const LevelMeta m = make_level_meta<D>(offsets, level, H);
+    const S *__restrict__ grid = table + (size_t)m.offset * C;
+
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float x[D];
+        src.get(b, x);
+        float frac[D];
+        uint32_t pg[D];
+        locate<D>(x, m.scale, frac, pg);
+
+        float w[1u << D];
+        float v[1u << D][C];
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); ++c) {
+            uint32_t pl[D];
+            w[c] = corner<D>(c, frac, pg, pl);
+            load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, v[c]);
+        }
+        float acc[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); ++c)
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ++ch) acc[ch] = __fmaf_rn(w[c], v[c][ch], acc[ch]);
+
+        S *out = blc_layout ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
+        store_vec<T, C>(out, acc);
+
+        if (dy_dx != nullptr) {   // hashencoder.cu:153-197 ([B,L,D,C]; like the reference without the x scale factor)
+            S *dst = dy_dx + ((size_t)b * L + level) * D * C;
+#pragma unroll
+            for (uint32_t gd = 0; gd < D; ++gd) {
+                float g[C];
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ++ch) g[ch] = 0.0f;
+#pragma unroll
+                for (uint32_t c = 0; c < (1u << (D - 1)); ++c) {
+                    float wc = 1.0f;
+                    uint32_t pl[D];
+#pragma unroll
+                    for (uint32_t nd = 0; nd < D - 1; ++nd) {
+                        const uint32_t d = nd >= gd ? nd + 1 : nd;
+                        if ((c >> nd) & 1u) { wc *= frac[d]; pl[d] = pg[d] + 1u; }
+                        else                { wc *= 1.0f - frac[d]; pl[d] = pg[d]; }
+                    }
+                    float lo[C], hi[C];
+                    pl[gd] = pg[gd];
+                    load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, lo);
+                    pl[gd] = pg[gd] + 1u;
+                    load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, hi);
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) g[ch] = __fmaf_rn(wc, hi[ch] - lo[ch], g[ch]);
+                }
+                store_vec<T, C>(dst + gd * C, g);
+            }
+        }
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------
+// One lane = one (point, level); all C channels of a corner are added by the same lane with back-to-back
+// atomics so the C floats of a row land in one 4*C-byte segment.  fp32 accumulation whatever the table type.
+template <typename T, uint32_t D, uint32_t C, typename Src>
+__global__ void __launch_bounds__(256)
+hash_backward_kernel(Src src, const typename T::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
+                     float *__restrict__ grad_table, uint32_t B, uint32_t L, uint32_t H, bool blc_layout) {
+    const uint32_t level = blockIdx.y;
+    const LevelMeta m = make_level_meta<D>(offsets, level, H);
+    float *__restrict__ gg = grad_table + (size_t)m.offset * C;
+
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float x[D];
+        src.get(b, x);
+        float frac[D];
+        uint32_t pg[D];
+        locate<D>(x, m.scale, frac, pg);
+        float g[C];
+        load_vec<T, C>(blc_layout ? grad + ((size_t)b * L + level) * C : grad + ((size_t)level * B + b) * C, g);
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); ++c) {
+            uint32_t pl[D];
+            const float w = corner<D>(c, frac, pg, pl);
+            float *dst = gg + (size_t)grid_row<D>(m, pl) * C;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(dst + ch, w * g[ch]);
+        }
+    }
+}
+
+static inline uint32_t hash_grid_x(uint32_t B) {
+    return (uint32_t)std::min<uint64_t>(((uint64_t)B + 255) / 256, 1u << 20);
+}
+
+}  // namespace naf

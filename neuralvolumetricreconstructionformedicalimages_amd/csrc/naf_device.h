@@ -1,0 +1,213 @@
+// naf_device.h -- device-side helpers shared by the gfx950 kernels of libnaf_hip.so.
+//
+// Index / position arithmetic follows reference src/encoder/hashencoder/src/hashencoder.cu:36-74,99-111
+// bit for bit (uint32 wrap-around of the dense stride included).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace naf {
+
+constexpr uint32_t kPrime1 = 19349663u;
+constexpr uint32_t kPrime2 = 83492791u;
+
+// How `index % hashmap_size` is evaluated for a level; decided once per level on the scalar unit.
+enum IndexMode : uint32_t {
+    kDenseNoMod = 0,  // dense strides, largest reachable index < T  -> the modulo is the identity
+    kDenseMask = 1,   // dense (possibly uint32-wrapped) strides, T is a power of two -> mask
+    kDenseMod = 2,    // dense, general T -> real modulo
+    kHashMask = 3,    // xor-prime hash, T is a power of two -> mask
+    kHashMod = 4      // xor-prime hash, general T
+};
+
+struct LevelMeta {
+    uint32_t offset;  // first row of the level in the table
+    uint32_t size;    // T_l  rows in the level
+    uint32_t stride1; // uint32-wrapped stride of dim 1  ((res+1)   mod 2^32)
+    uint32_t stride2; // uint32-wrapped stride of dim 2  ((res+1)^2 mod 2^32)
+    uint32_t mode;    // IndexMode
+    float scale;      // 2^l * H - 1           (hashencoder.cu:99)
+};
+
+// All inputs are wave-uniform; the compiler keeps this on the scalar ALU.
+template <uint32_t D>
+__device__ __forceinline__ LevelMeta make_level_meta(const int32_t *__restrict__ offsets, uint32_t level, uint32_t H) {
+    LevelMeta m;
+    m.offset = (uint32_t)offsets[level];
+    m.size = (uint32_t)offsets[level + 1] - m.offset;
+    m.scale = exp2f((float)level) * (float)H - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(m.scale) + 1u;          // hashencoder.cu:100
+    // replay the stride loop of get_grid_index (hashencoder.cu:59-64)
+    uint32_t stride = 1;
+    uint64_t max_index = 0;  // largest index reachable without wrap, for the no-mod proof
+    bool wrapped = false;
+    uint32_t strides[3] = {1u, 0u, 0u};
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        if (stride <= m.size) {
+            strides[d] = stride;
+            max_index += (uint64_t)res * stride;
+            const uint64_t wide = (uint64_t)stride * (res + 1u);
+            wrapped = wrapped || (wide >> 32) != 0;
+            stride = (uint32_t)wide;
+        } else {
+            strides[d] = 0u;  // dims past the cut are not accumulated (only matters when hashed anyway)
+        }
+    }
+    m.stride1 = strides[1];
+    m.stride2 = D > 2 ? strides[2] : 0u;
+    const bool hashed = stride > m.size;
+    const bool pow2 = (m.size & (m.size - 1u)) == 0u;
+    if (hashed) m.mode = pow2 ? kHashMask : kHashMod;
+    else if (!wrapped && max_index < (uint64_t)m.size) m.mode = kDenseNoMod;
+    else m.mode = pow2 ? kDenseMask : kDenseMod;
+    return m;
+}
+
+// hashencoder.cu:55-74 with the level regime pre-decoded.  Returns the row (not multiplied by C).
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_row(const LevelMeta &m, const uint32_t (&p)[D]) {
+    uint32_t idx;
+    if (m.mode >= kHashMask) {
+        idx = p[0];                         // prime 1
+        idx ^= p[1] * kPrime1;
+        if constexpr (D > 2) idx ^= p[2] * kPrime2;
+    } else {
+        idx = p[0] + p[1] * m.stride1;
+        if constexpr (D > 2) idx += p[2] * m.stride2;
+    }
+    if (m.mode == kDenseMask || m.mode == kHashMask) idx &= (m.size - 1u);
+    else if (m.mode != kDenseNoMod) idx %= m.size;
+    return idx;
+}
+
+// hashencoder.cu:106-111.  nvcc contracts x*scale+0.5 into an FMA; we ask for it explicitly.
+template <uint32_t D>
+__device__ __forceinline__ void locate(const float (&x)[D], float scale, float (&frac)[D], uint32_t (&pg)[D]) {
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        const float pos = __fmaf_rn(x[d], scale, 0.5f);
+        const float fl = floorf(pos);
+        pg[d] = (uint32_t)fl;
+        frac[d] = pos - fl;
+    }
+}
+
+// corner weight / coordinates, d = 0..D-1 product order as in hashencoder.cu:122-133
+template <uint32_t D>
+__device__ __forceinline__ float corner(uint32_t c, const float (&frac)[D], const uint32_t (&pg)[D], uint32_t (&pl)[D]) {
+    float w = 1.0f;
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        if ((c >> d) & 1u) { w *= frac[d]; pl[d] = pg[d] + 1u; }
+        else               { w *= 1.0f - frac[d]; pl[d] = pg[d]; }
+    }
+    return w;
+}
+
+// ---- storage types ---------------------------------------------------------------------------
+struct F32 { using store_t = float; };
+struct F16 { using store_t = _Float16; };
+struct BF16 { using store_t = uint16_t; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even, NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Conv;
+template <> struct Conv<F32> {
+    static __device__ __forceinline__ float load(const float *p) { return *p; }
+    static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+};
+template <> struct Conv<F16> {
+    static __device__ __forceinline__ float load(const _Float16 *p) { return (float)*p; }
+    static __device__ __forceinline__ void store(_Float16 *p, float v) { *p = (_Float16)v; }
+};
+template <> struct Conv<BF16> {
+    static __device__ __forceinline__ float load(const uint16_t *p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(uint16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+
+// Vector load/store of C consecutive table elements as fp32 (C*sizeof(store_t) is 2..32 bytes, naturally aligned).
+template <typename T, uint32_t C>
+__device__ __forceinline__ void load_vec(const typename T::store_t *p, float (&v)[C]) {
+    using S = typename T::store_t;
+    constexpr uint32_t bytes = C * sizeof(S);
+    if constexpr (bytes == 2) {
+        v[0] = Conv<T>::load(p);
+    } else if constexpr (bytes == 4) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t *>(p);
+        if constexpr (sizeof(S) == 4) v[0] = __uint_as_float(raw);
+        else { S e[2]; __builtin_memcpy(e, &raw, 4); v[0] = Conv<T>::load(&e[0]); v[1] = Conv<T>::load(&e[1]); }
+    } else if constexpr (bytes == 8) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        S e[8 / sizeof(S)]; __builtin_memcpy(e, &raw, 8);
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) v[c] = Conv<T>::load(&e[c]);
+    } else if constexpr (bytes == 16) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(p);
+        S e[16 / sizeof(S)]; __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) v[c] = Conv<T>::load(&e[c]);
+    } else {  // 32 bytes: two 16-byte halves
+        const uint4 r0 = reinterpret_cast<const uint4 *>(p)[0];
+        const uint4 r1 = reinterpret_cast<const uint4 *>(p)[1];
+        S e[32 / sizeof(S)]; __builtin_memcpy(e, &r0, 16); __builtin_memcpy(e + 16 / sizeof(S), &r1, 16);
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) v[c] = Conv<T>::load(&e[c]);
+    }
+}
+
+template <typename T, uint32_t C>
+__device__ __forceinline__ void store_vec(typename T::store_t *p, const float (&v)[C]) {
+    using S = typename T::store_t;
+    constexpr uint32_t bytes = C * sizeof(S);
+    S e[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) Conv<T>::store(&e[c], v[c]);
+    if constexpr (bytes == 2) { *p = e[0]; }
+    else if constexpr (bytes == 4) { uint32_t raw; __builtin_memcpy(&raw, e, 4); *reinterpret_cast<uint32_t *>(p) = raw; }
+    else if constexpr (bytes == 8) { uint2 raw; __builtin_memcpy(&raw, e, 8); *reinterpret_cast<uint2 *>(p) = raw; }
+    else if constexpr (bytes == 16) { uint4 raw; __builtin_memcpy(&raw, e, 16); *reinterpret_cast<uint4 *>(p) = raw; }
+    else {
+        uint4 r0, r1; __builtin_memcpy(&r0, e, 16); __builtin_memcpy(&r1, e + 16 / sizeof(S), 16);
+        reinterpret_cast<uint4 *>(p)[0] = r0; reinterpret_cast<uint4 *>(p)[1] = r1;
+    }
+}
+
+// ---- counter-based jitter (used when the caller passes no t_rand) --------------------------------
+// splitmix64-style finaliser over (seed, global ray index, sample); 24 random bits -> [0,1).
+__device__ __host__ __forceinline__ float jitter(uint64_t seed, uint32_t ray, uint32_t sample) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((((uint64_t)ray) << 32) | (uint64_t)sample) + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---- stratified depth of sample s on a ray (render.py:87-100) ------------------------------------
+// torch.linspace(0,1,S) on CPU/GPU evaluates start + i*step for i < S/2 and end - (S-1-i)*step above.
+__device__ __forceinline__ float lin_t(uint32_t i, uint32_t S) {
+    const float step = 1.0f / (float)(S - 1u);
+    // the upper half is a fused multiply-subtract in torch's CPU and CUDA builds (checked against torch.linspace)
+    return (i < S / 2u) ? (float)i * step : __fmaf_rn(-(float)(S - 1u - i), step, 1.0f);
+}
+__device__ __forceinline__ float base_z(float near, float far, uint32_t i, uint32_t S) {
+    const float t = lin_t(i, S);
+    return near * (1.0f - t) + far * t;      // two roundings like the reference (no fma)
+}
+// jittered depth; u is the uniform for this sample (ignored when !perturb)
+__device__ __forceinline__ float sample_z(float near, float far, uint32_t i, uint32_t S, bool perturb, float u) {
+    const float z = base_z(near, far, i, S);
+    if (!perturb) return z;
+    const float lower = i == 0u ? z : 0.5f * (z + base_z(near, far, i - 1u, S));
+    const float upper = i + 1u == S ? z : 0.5f * (base_z(near, far, i + 1u, S) + z);
+    return lower + (upper - lower) * u;
+}
+
+}  // namespace naf

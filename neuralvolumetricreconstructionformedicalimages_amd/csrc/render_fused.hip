@@ -1,0 +1,577 @@
+// render_fused.hip -- fused NAF ray-march pipeline for gfx950: rays -> samples -> hash features -> sigma-MLP (MFMA)
+// -> attenuation line integral -> masked MSE gradient -> MLP backward (MFMA) -> hash-table scatter.
+//
+// Replaces the ATen / cuBLAS kernel soup behind reference src/render/render.py:82-212, src/network/network.py:34-58,
+// src/loss/loss.py:37-39 and the autograd of train.py:69-127.  Points are never materialised: every kernel recomputes
+// its sample position from the 32-byte ray record and the jitter (explicit t_rand or the counter-based generator).
+//
+// Kernels of one training step (B = n_rays * S points, feature tensors are [L, B, C]):
+//   1 hash_forward_kernel<SrcRays>   gathers  -> feat                 (hash_kernels.h)
+//   2 mlp_forward_kernel             feat -> sigma -> acc[r]          one wave per ray, wave-reduced line integral
+//   3 mlp_backward_kernel            feat, acc, target -> dfeat, per-workgroup dW slabs, loss
+//   4 hash_backward_kernel<SrcRays>  dfeat -> grad table (fp32 atomics)
+//   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=)
+#include <algorithm>
+
+#include "naf_host.h"
+#include "hash_kernels.h"
+#include "field_mlp.h"
+
+namespace naf {
+
+// ---- feature tile I/O ------------------------------------------------------------------------------------
+// Lane (n,h) owns features f = 8q + 4h + i (q,i = 0..3) of point p; feature f is channel f % C of level f / C.
+template <typename FT, uint32_t C>
+__device__ __forceinline__ void load_feat_slots(const typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
+                                                uint32_t h, float (&x)[16]) {
+    constexpr uint32_t V = C < 4 ? C : 4;     // contiguous channels per access
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q)
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i += V) {
+            const uint32_t f = 8u * q + 4u * h + i;
+            float v[V];
+            load_vec<FT, V>(feat + ((size_t)(f / C) * B + p) * C + (f % C), v);
+#pragma unroll
+            for (uint32_t k = 0; k < V; ++k) x[4 * q + i + k] = v[k];
+        }
+}
+template <typename FT, uint32_t C>
+__device__ __forceinline__ void store_feat_slots(typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
+                                                 uint32_t h, const float (&x)[16]) {
+    constexpr uint32_t V = C < 4 ? C : 4;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q)
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i += V) {
+            const uint32_t f = 8u * q + 4u * h + i;
+            float v[V];
+#pragma unroll
+            for (uint32_t k = 0; k < V; ++k) v[k] = x[4 * q + i + k];
+            store_vec<FT, V>(feat + ((size_t)(f / C) * B + p) * C + (f % C), v);
+        }
+}
+
+__device__ __forceinline__ float wave_sum32(float v) {   // sum over the 32 lanes that share a lane half
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// dist of sample s on ray r (render.py:192-194): (z[s+1]-z[s]) * |d|, last sample 1e-10 * |d|
+__device__ __forceinline__ float sample_dist(const SrcRays &src, uint32_t r, uint32_t s, float near, float far, float dnorm) {
+    if (s + 1u >= src.S) return 1e-10f * dnorm;
+    return (src.depth(r, s + 1u, near, far) - src.depth(r, s, near, far)) * dnorm;
+}
+
+// ---- 2: MLP forward + line integral ----------------------------------------------------------------------
+// kRays: one wave per ray, acc[r] = sum_s sigma*dist.   !kRays: plain point list, out[p] = sigma(p).
+template <typename P, uint32_t C, bool kRays>
+__global__ void __launch_bounds__(256)
+mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
+                   float *__restrict__ out, uint32_t n_items, uint32_t B, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MlpShared<P>::build(smem, mlp, 4);
+    const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    typename P::Frag x0f;
+    float x0[16], h1[16], h2[16], h3[16];
+
+    if constexpr (kRays) {
+        const uint32_t S = src.S, tiles = (S + 31u) / 32u;
+        for (uint32_t r = wave; r < n_items; r += n_waves) {
+            const float *ray = src.rays + (size_t)r * 8;
+            const float near = ray[6], far = ray[7];
+            const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+            float part = 0.0f;
+            for (uint32_t k = 0; k < tiles; ++k) {
+                const uint32_t s = 32u * k + n;
+                const bool valid = s < S;
+                const uint32_t p = r * S + (valid ? s : S - 1u);
+                load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
+                const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
+                const float sigma = last_act(act, z4);
+                if (valid && h == 0) part += sigma * sample_dist(src, r, s, near, far, dnorm);
+            }
+            part = wave_sum32(part);
+            if (lane == 0) out[r] = part;
+        }
+    } else {
+        const uint32_t tiles = (n_items + 31u) / 32u;
+        for (uint32_t k = wave; k < tiles; k += n_waves) {
+            const uint32_t p0 = 32u * k + n;
+            const bool valid = p0 < n_items;
+            const uint32_t p = valid ? p0 : n_items - 1u;
+            load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
+            const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
+            if (valid && h == 0) out[p] = last_act(act, z4);
+        }
+    }
+}
+
+// ---- 3: MLP backward --------------------------------------------------------------------------------------
+// slab layout == parameter block layout (kW0 .. kB3), one slab of kSlabStride floats per workgroup.
+constexpr uint32_t kSlabStride = 4352;
+
+template <typename P>
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename P, uint32_t C>
+__global__ void __launch_bounds__(256)
+mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
+                    const float *__restrict__ grad_acc, typename P::feat_t::store_t *__restrict__ dfeat,
+                    float *__restrict__ slabs, uint32_t n_rays, uint32_t B, int act) {
+    using Sh = MlpShared<P>;
+    using TR = typename P::tr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Sh::build(smem, mlp, 8);
+    const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5, wib = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    constexpr uint32_t kImg = 32u * P::kTrPitch;                                  // elements per transpose image
+    constexpr uint32_t kShAligned = (Sh::kBytes + 15u) & ~15u;
+    TR *imgA = reinterpret_cast<TR *>(smem + kShAligned) + (size_t)wib * 3u * kImg;   // gradient tile  G
+    TR *imgB = imgA + kImg;                                                        // input tile     X0
+    TR *imgC = imgB + kImg;                                                        // hidden tile    H2 / H1
+
+    // weight-gradient accumulators: lane (c,h), register t  <->  dW[out = slot_row(t,h)][in = c]
+    f32x16 dW0 = {0}, dW1 = {0}, dW2a = {0}, dW2b = {0};
+    float db0 = 0.0f, db1 = 0.0f, db2 = 0.0f, db3 = 0.0f;
+    float dw3[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dw3[t] = 0.0f;
+    float w3s[16];
+    Sh::slot_vector(smem, 3, h, w3s);
+
+    const uint32_t S = src.S, tiles = (S + 31u) / 32u;
+    for (uint32_t r = wave; r < n_rays; r += n_waves) {
+        const float *ray = src.rays + (size_t)r * 8;
+        const float near = ray[6], far = ray[7];
+        const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+        const float dacc = grad_acc[r];
+
+        for (uint32_t k = 0; k < tiles; ++k) {
+            const uint32_t s = 32u * k + n;
+            const bool valid = s < S;
+            const uint32_t p = r * S + (valid ? s : S - 1u);
+            float x0[16], h1[16], h2[16], h3[16];
+            typename P::Frag x0f;
+            load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
+            const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
+            const float sigma = last_act(act, z4);
+            const float gsig = valid ? dacc * sample_dist(src, r, s, near, far, dnorm) : 0.0f;
+            const float g4 = gsig * last_act_grad(act, z4, sigma);
+
+            // output layer: dw3 += g4 * h3, db3 += g4 ; G3 = (w3 g4) * lrelu'(z3)
+            float g[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                dw3[t] = __fmaf_rn(g4, h3[t], dw3[t]);
+                g[t] = w3s[t] * g4 * (h3[t] > 0.0f ? 1.0f : kLeaky);
+            }
+            if (h == 0) db3 += g4;
+
+            // transpose G3, X0, H2 through LDS: image row = feature, column = point of the tile
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t row = slot_row(t, h);
+                P::tr_store(imgA, row, n, g[t]);
+                P::tr_store(imgB, row, n, x0[t]);
+                P::tr_store(imgC, row, n, h2[t]);
+            }
+            wave_lds_fence<P>();
+            typename P::Frag gA = P::tr_load(imgA, n, h);             // A[m = out][k = point]
+            const typename P::Frag xB = P::tr_load(imgB, n, h);        // B[k = point][n = in]
+            typename P::Frag hB = P::tr_load(imgC, n, h);
+            dW2a = P::mma(gA, xB, dW2a);
+            dW2b = P::mma(gA, hB, dW2b);
+            db2 += P::frag_sum(gA);
+            wave_lds_fence<P>();
+
+            // back through layer 2 (skip layer): d[input] and d[h2]
+            const typename P::Frag g3f = P::pack(g);
+            f32x16 zero = {0};
+            f32x16 dx0 = P::mma(P::load_wfrag(smem, kFW2aT, lane), g3f, zero);
+            f32x16 dh = P::mma(P::load_wfrag(smem, kFW2bT, lane), g3f, zero);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) g[t] = dh[t] * (h2[t] > 0.0f ? 1.0f : kLeaky);      // G2
+
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t row = slot_row(t, h);
+                P::tr_store(imgA, row, n, g[t]);
+                P::tr_store(imgC, row, n, h1[t]);
+            }
+            wave_lds_fence<P>();
+            gA = P::tr_load(imgA, n, h);
+            hB = P::tr_load(imgC, n, h);
+            dW1 = P::mma(gA, hB, dW1);
+            db1 += P::frag_sum(gA);
+            wave_lds_fence<P>();
+
+            dh = P::mma(P::load_wfrag(smem, kFW1T, lane), P::pack(g), zero);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) g[t] = dh[t] * (h1[t] > 0.0f ? 1.0f : kLeaky);      // G1
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) P::tr_store(imgA, slot_row(t, h), n, g[t]);
+            wave_lds_fence<P>();
+            gA = P::tr_load(imgA, n, h);
+            dW0 = P::mma(gA, xB, dW0);
+            db0 += P::frag_sum(gA);
+            wave_lds_fence<P>();
+
+            dx0 = P::mma(P::load_wfrag(smem, kFW0T, lane), P::pack(g), dx0);
+            if (valid) {
+                float o[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[t] = dx0[t];
+                store_feat_slots<typename P::feat_t, C>(dfeat, B, p, h, o);
+            }
+        }
+    }
+
+    // ---- fold the 4 waves of the workgroup into one slab (fixed order -> deterministic), then one store ------
+    __syncthreads();                                        // everyone is done with the transpose images
+    float *red = reinterpret_cast<float *>(smem + kShAligned);          // kSlabStride floats, reuses the images
+    // per-lane partial sums that still need a cross-lane reduction
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dw3[t] = wave_sum32(dw3[t]);          // over the 32 points of a lane half
+    db0 += __shfl_xor(db0, 32, 64);                                     // the two lane halves hold 16 points each
+    db1 += __shfl_xor(db1, 32, 64);
+    db2 += __shfl_xor(db2, 32, 64);
+    db3 = wave_sum32(db3) ;
+    db3 += __shfl_xor(db3, 32, 64);
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+        if (wib == w) {
+            const bool first = w == 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t o = slot_row(t, h);
+                const uint32_t i0 = kW0 + o * 32u + n, i1 = kW1 + o * 32u + n, i2 = kW2 + o * 64u + n;
+                red[i0] = (first ? 0.0f : red[i0]) + dW0[t];
+                red[i1] = (first ? 0.0f : red[i1]) + dW1[t];
+                red[i2] = (first ? 0.0f : red[i2]) + dW2a[t];
+                red[i2 + 32u] = (first ? 0.0f : red[i2 + 32u]) + dW2b[t];
+                if (n == 0) red[kW3 + o] = (first ? 0.0f : red[kW3 + o]) + dw3[t];
+            }
+            if (h == 0) {                                    // db*: lane n holds the sum for feature n
+                red[kB0 + n] = (first ? 0.0f : red[kB0 + n]) + db0;
+                red[kB1 + n] = (first ? 0.0f : red[kB1 + n]) + db1;
+                red[kB2 + n] = (first ? 0.0f : red[kB2 + n]) + db2;
+            }
+            if (lane == 0) red[kB3] = (first ? 0.0f : red[kB3]) + db3;
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
+    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) slab[i] = red[i];
+}
+
+// masked squared error of train.py:127 / loss.py:37 in weighted form: loss = sum_r w_r (acc_r - y_r)^2,
+// grad_acc[r] = 2 w_r (acc_r - y_r).  One workgroup; the sum runs in a fixed order (deterministic).
+__global__ void __launch_bounds__(1024)
+loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target, const float *__restrict__ ray_weight,
+                 float *__restrict__ grad_acc, float *__restrict__ loss_out, uint32_t n_rays) {
+    __shared__ float part[16];
+    float s = 0.0f;
+    for (uint32_t r = threadIdx.x; r < n_rays; r += blockDim.x) {
+        const float err = acc[r] - target[r], w = ray_weight[r];
+        grad_acc[r] = 2.0f * w * err;
+        s += w * err * err;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out != nullptr) {
+        float t = 0.0f;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) t += part[i];
+        loss_out[0] += t;
+    }
+}
+
+// ---- 5: slabs -> grad_mlp (+=), summed in workgroup order (deterministic) -----------------------------------
+__global__ void __launch_bounds__(256)
+mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kMlpParams) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    uint32_t k = 0;
+    for (; k + 4 <= n_slabs; k += 4) {
+        s0 += slabs[(size_t)(k + 0) * kSlabStride + i];
+        s1 += slabs[(size_t)(k + 1) * kSlabStride + i];
+        s2 += slabs[(size_t)(k + 2) * kSlabStride + i];
+        s3 += slabs[(size_t)(k + 3) * kSlabStride + i];
+    }
+    for (; k < n_slabs; ++k) s0 += slabs[(size_t)k * kSlabStride + i];
+    grad_mlp[i] += (s0 + s1) + (s2 + s3);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+constexpr uint32_t kBackwardBlocks = 512;   // 2 workgroups of 4 waves per CU; also the number of dW slabs
+
+template <typename P>
+static uint32_t forward_lds_bytes() { return MlpShared<P>::kBytes; }
+template <typename P>
+static uint32_t backward_lds_bytes() {
+    const uint32_t sh = (MlpShared<P>::kBytes + 15u) & ~15u;
+    const uint32_t imgs = 4u * 3u * 32u * P::kTrPitch * (uint32_t)sizeof(typename P::tr_t);
+    return sh + std::max<uint32_t>(imgs, (kMlpParams + 1u) * 4u);
+}
+
+struct Workspace {
+    unsigned char *feat, *dfeat;
+    float *slabs, *grad_acc;
+    size_t bytes;
+};
+static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points) {
+    const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
+    const size_t feat_bytes = ((size_t)n_points * cfg->L * cfg->C * esz + 255) & ~(size_t)255;
+    const size_t slab_bytes = (size_t)kBackwardBlocks * kSlabStride * 4;
+    const size_t n_rays_max = (size_t)(n_points / std::max<uint32_t>(cfg->n_samples, 1u)) + 1;
+    Workspace w;
+    w.feat = (unsigned char *)base;
+    w.dfeat = w.feat + feat_bytes;
+    w.slabs = (float *)(w.dfeat + feat_bytes);
+    w.grad_acc = (float *)((unsigned char *)w.slabs + slab_bytes);
+    w.bytes = 2 * feat_bytes + slab_bytes + ((n_rays_max * 4 + 255) & ~(size_t)255);
+    return w;
+}
+
+static int check_cfg(const naf_render_cfg *cfg, const char *who) {
+    if (!cfg) return fail(NAF_ERR_INVALID_ARGUMENT, "render: null cfg");
+    if (cfg->L * cfg->C != 32u || !(cfg->C == 1 || cfg->C == 2 || cfg->C == 4 || cfg->C == 8))
+        return fail(NAF_ERR_UNSUPPORTED, "fused field: encoder output L*C must be 32 with C in {1,2,4,8} "
+                                         "(other shapes run through the unfused operators)");
+    if (cfg->mlp_precision != NAF_F32 && cfg->mlp_precision != NAF_BF16)
+        return fail(NAF_ERR_UNSUPPORTED, "fused field: mlp_precision must be NAF_F32 or NAF_BF16");
+    if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
+    if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
+    if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
+    (void)who;
+    return NAF_OK;
+}
+
+// Feature tensors are written in the MLP's operand precision: TT = table storage, P::feat_t = feature storage.
+// The encoder kernel is templated on one storage type for table and output, so when they differ the
+// features are produced by a converting instantiation below.
+template <typename TT, typename FT, uint32_t C, typename Src>
+__global__ void __launch_bounds__(256)
+encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H) {
+    const uint32_t level = blockIdx.y;
+    const LevelMeta m = make_level_meta<3>(offsets, level, H);
+    const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float x[3];
+        src.get(b, x);
+        float frac[3];
+        uint32_t pg[3];
+        locate<3>(x, m.scale, frac, pg);
+        float w[8], v[8][C];
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            uint32_t pl[3];
+            w[c] = corner<3>(c, frac, pg, pl);
+            load_vec<TT, C>(grid + (size_t)grid_row<3>(m, pl) * C, v[c]);
+        }
+        float a[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) a[ch] = 0.0f;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[c], v[c][ch], a[ch]);
+        store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
+    }
+}
+
+template <typename TT, typename P, uint32_t C, typename Src>
+static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+    using FT = typename P::feat_t;
+    hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H);
+    return check_launch("encode_kernel");
+}
+
+template <typename P, uint32_t C, typename Src>
+static int dispatch_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+    switch (cfg->table_dtype) {
+        case NAF_F32: return run_encode<F32, P, C>(src, table, offsets, feat, B, cfg, s);
+        case NAF_F16: return run_encode<F16, P, C>(src, table, offsets, feat, B, cfg, s);
+        default: return run_encode<BF16, P, C>(src, table, offsets, feat, B, cfg, s);
+    }
+}
+
+template <typename P, uint32_t C, bool kRays>
+static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &src, float *out, uint32_t n_items, uint32_t B,
+                           const naf_render_cfg *cfg, hipStream_t s) {
+    auto kern = mlp_forward_kernel<P, C, kRays>;
+    const uint32_t lds = forward_lds_bytes<P>();
+    const uint64_t waves_needed = kRays ? n_items : ((uint64_t)n_items + 31) / 32;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, 256u * 8u));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, n_items, B,
+                       cfg->last_activation);
+    return check_launch("mlp_forward_kernel");
+}
+
+template <typename P, uint32_t C>
+static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, void *dfeat,
+                            float *slabs, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+    auto kern = mlp_backward_kernel<P, C>;
+    const uint32_t lds = backward_lds_bytes<P>();
+    static bool attr_set = false;       // raise the dynamic-LDS cap once per instantiation (fp32 images need > 64 KiB)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(NAF_ERR_LAUNCH, "mlp_backward_kernel: cannot raise dynamic LDS limit");
+        attr_set = true;
+    }
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
+                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation);
+    if (int rc = check_launch("mlp_backward_kernel")) return rc;
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + 255) / 256), dim3(256), 0, s, slabs, grid, grad_mlp);
+    return check_launch("mlp_grad_reduce_kernel");
+}
+
+template <typename P, uint32_t C>
+static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                             const naf_render_cfg *cfg, hipStream_t s) {
+    using FT = typename P::feat_t;
+    hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
+                       (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false);
+    return check_launch("hash_backward_kernel");
+}
+
+static SrcRays make_src(const float *rays, const float *t_rand, const naf_render_cfg *cfg) {
+    SrcRays s;
+    s.rays = rays; s.t_rand = t_rand; s.S = cfg->n_samples; s.perturb = cfg->perturb != 0; s.bound = cfg->bound;
+    s.seed = cfg->seed; s.ray_base = cfg->ray_index_base;
+    return s;
+}
+
+template <typename P, uint32_t C>
+static int render_forward_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, const float *mlp,
+                               float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+    const uint32_t B = n_rays * cfg->n_samples;
+    const Workspace w = carve(ws, cfg, B);
+    const SrcRays src = make_src(rays, t_rand, cfg);
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    return run_mlp_forward<P, C, true>(w.feat, mlp, src, acc, n_rays, B, cfg, s);
+}
+
+template <typename P, uint32_t C>
+static int render_backward_impl(const float *rays, const float *t_rand, const float *grad_acc, const void *emb, const int32_t *offsets,
+                                const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
+                                void *ws, int features_valid, hipStream_t s) {
+    const uint32_t B = n_rays * cfg->n_samples;
+    const Workspace w = carve(ws, cfg, B);
+    const SrcRays src = make_src(rays, t_rand, cfg);
+    if (!features_valid)
+        if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, grad_mlp, n_rays, B, cfg, s)) return rc;
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, s);
+}
+
+template <typename P, uint32_t C>
+static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
+                             const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
+                             uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+    if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
+    const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(1), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, n_rays);
+    if (int rc = check_launch("loss_grad_kernel")) return rc;
+    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, s);
+}
+
+template <typename P, uint32_t C>
+static int field_forward_impl(const float *pts, const void *emb, const int32_t *offsets, const float *mlp, float *sigma, uint32_t B,
+                              const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+    const Workspace w = carve(ws, cfg, B);
+    SrcRaw src{pts, cfg->bound};
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    SrcRays none{};
+    return run_mlp_forward<P, C, false>(w.feat, mlp, none, sigma, B, B, cfg, s);
+}
+
+#define NAF_DISPATCH_PC(FN, ...)                                                                      \
+    do {                                                                                              \
+        if (cfg->mlp_precision == NAF_F32) {                                                          \
+            switch (cfg->C) {                                                                         \
+                case 1: return FN<PrecF32, 1>(__VA_ARGS__);                                           \
+                case 2: return FN<PrecF32, 2>(__VA_ARGS__);                                           \
+                case 4: return FN<PrecF32, 4>(__VA_ARGS__);                                           \
+                default: return FN<PrecF32, 8>(__VA_ARGS__);                                          \
+            }                                                                                         \
+        }                                                                                             \
+        switch (cfg->C) {                                                                             \
+            case 1: return FN<PrecBF16, 1>(__VA_ARGS__);                                              \
+            case 2: return FN<PrecBF16, 2>(__VA_ARGS__);                                              \
+            case 4: return FN<PrecBF16, 4>(__VA_ARGS__);                                              \
+            default: return FN<PrecBF16, 8>(__VA_ARGS__);                                             \
+        }                                                                                             \
+    } while (0)
+
+}  // namespace naf
+
+using namespace naf;
+
+extern "C" size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
+    if (!cfg) return 0;
+    return carve(nullptr, cfg, n_points).bytes;
+}
+
+static int check_points(uint64_t n_points) {
+    if (n_points >= (1ull << 31)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: more than 2^31 points per call; split the batch");
+    return NAF_OK;
+}
+
+extern "C" int naf_render_forward(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
+                                  const float *mlp, float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
+                                  void *stream) {
+    if (int rc = check_cfg(cfg, "render_forward")) return rc;
+    if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    NAF_DISPATCH_PC(render_forward_impl, rays, t_rand, embeddings, offsets, mlp, acc, n_rays, cfg, workspace, (hipStream_t)stream);
+}
+
+extern "C" int naf_render_backward(const float *rays, const float *t_rand, const float *grad_acc, const void *embeddings,
+                                   const int32_t *offsets, const float *mlp, float *grad_embeddings, float *grad_mlp,
+                                   uint32_t n_rays, const naf_render_cfg *cfg, void *workspace, int features_valid, void *stream) {
+    if (int rc = check_cfg(cfg, "render_backward")) return rc;
+    if (!rays || !grad_acc || !embeddings || !offsets || !mlp || !grad_embeddings || !grad_mlp || !workspace)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    NAF_DISPATCH_PC(render_backward_impl, rays, t_rand, grad_acc, embeddings, offsets, mlp, grad_embeddings, grad_mlp, n_rays, cfg,
+                    workspace, features_valid, (hipStream_t)stream);
+}
+
+extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                const naf_render_cfg *cfg, void *workspace, void *stream) {
+    if (int rc = check_cfg(cfg, "render_train")) return rc;
+    if (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
+                    loss_out, n_rays, cfg, workspace, (hipStream_t)stream);
+}
+
+extern "C" int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,
+                                 float *sigma, uint32_t B, const naf_render_cfg *cfg, void *workspace, void *stream) {
+    if (int rc = check_cfg(cfg, "field_forward")) return rc;
+    if (!pts || !embeddings || !offsets || !mlp || !sigma || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward: null pointer");
+    if (int rc = check_points(B)) return rc;
+    if (B == 0) return NAF_OK;
+    NAF_DISPATCH_PC(field_forward_impl, pts, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);
+}

@@ -1,0 +1,114 @@
+"""Python front-end of the fused ray-march entry points of libnaf_hip.so (include/naf_hip.h):
+naf_render_forward / naf_render_backward / naf_render_train / naf_field_forward.
+
+The reference evaluates the same maths as ~40 ATen/cuBLAS launches per 200-ray chunk
+(src/render/render.py:82-212, src/network/network.py:34-58); here one call covers the whole ray batch.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _abi
+from .network import LAST_ACTIVATIONS
+
+_workspaces = {}
+_feature_gen = {}          # device -> generation counter of the features currently held by the workspace
+
+
+def _bump(device):
+    _feature_gen[device] = _feature_gen.get(device, 0) + 1
+    return _feature_gen[device]
+
+
+def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_base=0):
+    enc = net.encoder
+    table_dtype = _abi.dtype_code(enc.embeddings.dtype)
+    if mlp_precision is None:          # parity mode for fp32 tables, bf16 matrix cores for 16-bit tables
+        mlp_precision = _abi.F32 if table_dtype == _abi.F32 else _abi.BF16
+    return _abi.RenderCfg(n_samples=int(n_samples), perturb=int(bool(perturb)), bound=float(net.bound),
+                          L=enc.num_levels, C=enc.level_dim, H=enc.base_resolution, table_dtype=table_dtype,
+                          mlp_precision=int(mlp_precision), last_activation=LAST_ACTIVATIONS[net.last_activation],
+                          seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), reserved=0)
+
+
+def workspace(cfg, n_points, device):
+    """Grow-only scratch buffer per device (features, feature gradients, MLP-gradient slabs)."""
+    need = int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), int(n_points)))
+    buf = _workspaces.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspaces[device] = buf
+    return buf
+
+
+def _offsets(enc, device):
+    if enc.offsets.device != device:
+        enc.offsets = enc.offsets.to(device)
+    return enc.offsets
+
+
+class _FusedRender(Function):
+    """acc[r] = sum_s sigma(pts[r,s]) * dist[r,s]  with gradients for the hash table and the MLP block."""
+
+    @staticmethod
+    def forward(ctx, rays, t_rand, embeddings, mlp, offsets, cfg):
+        rays = rays.contiguous().float()
+        n_rays = rays.shape[0]
+        acc = torch.empty(n_rays, device=rays.device, dtype=torch.float32)
+        ws = workspace(cfg, n_rays * cfg.n_samples, rays.device)
+        mlp = mlp.contiguous()
+        emb = embeddings.contiguous()
+        _abi.check(_abi.lib().naf_render_forward(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(emb), _abi.ptr(offsets),
+                                                 _abi.ptr(mlp), _abi.ptr(acc), n_rays, ctypes.byref(cfg), _abi.ptr(ws),
+                                                 _abi.stream_ptr()), "render_forward")
+        ctx.save_for_backward(rays, t_rand, emb, mlp, offsets)
+        ctx.cfg = cfg
+        ctx.gen = _bump(rays.device)
+        ctx.ws_ptr = ws.data_ptr()
+        return acc
+
+    @staticmethod
+    def backward(ctx, grad_acc):
+        rays, t_rand, emb, mlp, offsets = ctx.saved_tensors
+        cfg = ctx.cfg
+        n_rays = rays.shape[0]
+        grad_emb = torch.zeros(emb.shape, device=emb.device, dtype=torch.float32)
+        grad_mlp = torch.zeros(_abi.MLP_PARAMS, device=emb.device, dtype=torch.float32)
+        ws = workspace(cfg, n_rays * cfg.n_samples, rays.device)
+        # the features are still in the workspace iff nobody rendered (or re-allocated it) in between
+        valid = int(ws.data_ptr() == ctx.ws_ptr and _feature_gen.get(rays.device) == ctx.gen)
+        grad_acc = grad_acc.contiguous().float()
+        _abi.check(_abi.lib().naf_render_backward(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(grad_acc), _abi.ptr(emb),
+                                                  _abi.ptr(offsets), _abi.ptr(mlp), _abi.ptr(grad_emb), _abi.ptr(grad_mlp),
+                                                  n_rays, ctypes.byref(cfg), _abi.ptr(ws), valid, _abi.stream_ptr()),
+                   "render_backward")
+        return None, None, grad_emb.to(emb.dtype), grad_mlp, None, None
+
+
+def fused_render(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_precision=None):
+    """Differentiable fused render of `rays` [n,8] through `net` (a fused_supported() DensityNetwork) -> acc [n]."""
+    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed)
+    return _FusedRender.apply(rays, t_rand, net.encoder.embeddings, net.packed_mlp(), _offsets(net.encoder, rays.device), cfg)
+
+
+@torch.no_grad()
+def field_query(net, pts, mlp_precision=None):
+    """sigma(pts) for a point cloud [..., 3] in [-bound, bound] -> [..., 1] (volume query, train.py:246-250)."""
+    enc = net.encoder
+    flat = pts.reshape(-1, 3).contiguous().float()
+    B = flat.shape[0]
+    if enc.strict_range:
+        enc._normalize(flat, net.bound)          # raises ValueError like hashgrid.py:122-123
+    cfg = render_cfg(net, 2, False, mlp_precision)
+    ws = workspace(cfg, B, flat.device)
+    sigma = torch.empty(B, device=flat.device, dtype=torch.float32)
+    mlp = net.packed_mlp().contiguous()
+    emb = enc.embeddings.detach().contiguous()
+    _abi.check(_abi.lib().naf_field_forward(_abi.ptr(flat), _abi.ptr(emb), _abi.ptr(_offsets(enc, flat.device)), _abi.ptr(mlp),
+                                            _abi.ptr(sigma), B, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()),
+               "field_forward")
+    _bump(flat.device)          # a pending _FusedRender.backward must recompute its features
+    return sigma.reshape(list(pts.shape[:-1]) + [1])

@@ -1,0 +1,175 @@
+"""Renderer: host-side mirror of reference src/render/render.py over libnaf_hip.so.
+
+Same call surface and return keys as the reference:
+    render(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_noise_std, chunk_size=None)
+        -> {"acc", "pts", ["tv_loss"], ["acc0", "weights0", "pts0"]}                      (render.py:31-146)
+    run_network(inputs, fn, netchunk)                                                     (render.py:148-156)
+    raw2outputs(raw, z_vals, rays_d, raw_noise_std)  -> acc, weights                      (render.py:178-212)
+    sample_pdf(bins, weights, N_samples, det)                                             (render.py:215-247)
+One optional extra keyword, `t_rand`, lets a caller pass the stratified jitter explicitly (the reference draws
+torch.rand inside render_chunk, render.py:99) so runs can be reproduced against the oracle.
+
+Execution: when `net` is the canonical NAF network and there is no fine pass the whole chunk is one fused call
+(hash gather -> MFMA MLP -> wave-reduced line integral); otherwise sampling and integration are the stand-alone
+HIP operators and the network runs through `run_network` exactly like the reference.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _abi
+from .fused import fused_render
+
+RETURN_PTS = True        # the reference always returns the sample points; switch off to save n*S*12 bytes
+CHECK_NUMERICS = True    # render.py:141-144 prints on NaN/Inf (costs one host sync per chunk)
+
+
+def _sample(rays, n_samples, perturb, bound, t_rand):
+    n = rays.shape[0]
+    z = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32)
+    pts = torch.empty(n, n_samples, 3, device=rays.device, dtype=torch.float32)
+    _abi.check(_abi.lib().naf_sample_rays(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(z), _abi.ptr(pts), n, n_samples,
+                                          int(bool(perturb)), float(bound), 0, 0, _abi.stream_ptr()), "sample_rays")
+    return z, pts
+
+
+class _Integrate(Function):
+    """acc[r] = sum_s sigma[r,s] * dist[r,s]   (render.py:192-201)."""
+
+    @staticmethod
+    def forward(ctx, sigma, z_vals, rays):
+        sigma = sigma.contiguous().float()
+        n, S = sigma.shape
+        acc = torch.empty(n, device=sigma.device, dtype=torch.float32)
+        _abi.check(_abi.lib().naf_integrate_forward(_abi.ptr(sigma), _abi.ptr(z_vals), _abi.ptr(rays), _abi.ptr(acc), n, S,
+                                                    _abi.stream_ptr()), "integrate_forward")
+        ctx.save_for_backward(z_vals, rays)
+        ctx.shape = (n, S)
+        return acc
+
+    @staticmethod
+    def backward(ctx, grad_acc):
+        z_vals, rays = ctx.saved_tensors
+        n, S = ctx.shape
+        grad_sigma = torch.empty(n, S, device=grad_acc.device, dtype=torch.float32)
+        grad_acc = grad_acc.contiguous().float()
+        _abi.check(_abi.lib().naf_integrate_backward(_abi.ptr(grad_acc), _abi.ptr(z_vals), _abi.ptr(rays), _abi.ptr(grad_sigma),
+                                                     n, S, _abi.stream_ptr()), "integrate_backward")
+        return grad_sigma, None, None
+
+
+def run_network(inputs, fn, netchunk):
+    uvt_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    out_flat = torch.cat([fn(uvt_flat[i:i + netchunk]) for i in range(0, uvt_flat.shape[0], netchunk)], 0)
+    return out_flat.reshape(list(inputs.shape[:-1]) + [out_flat.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0.0):
+    if raw_noise_std > 0.0:
+        raw0 = raw[..., 0] + torch.randn(raw[..., 0].shape, device=raw.device) * raw_noise_std
+    else:
+        raw0 = raw[..., 0]
+    if raw.is_cuda:
+        rays = torch.zeros(rays_d.shape[0], 8, device=raw.device, dtype=torch.float32)
+        rays[:, 3:6] = rays_d
+        acc = _Integrate.apply(raw0, z_vals.contiguous().float(), rays)
+    else:
+        raise RuntimeError("raw2outputs: tensors must live on the GPU (no CPU path)")
+    if raw.shape[-1] == 1:
+        eps = torch.ones_like(raw[:, :1, -1]) * 1e-10
+        weights = torch.cat([eps, torch.abs(raw[:, 1:, -1] - raw[:, :-1, -1])], dim=-1)
+        weights = weights / torch.max(weights)
+    elif raw.shape[-1] == 2:
+        weights = raw[..., 1] / torch.max(raw[..., 1])
+    else:
+        raise NotImplementedError("Wrong raw shape")
+    return acc, weights
+
+
+def sample_pdf(bins, weights, N_samples, det=False):
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.0, 1.0, steps=N_samples, device=cdf.device).expand(list(cdf.shape[:-1]) + [N_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=cdf.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    inds_g = torch.stack([below, above], -1)
+    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+def _points(rays, z_vals, bound):
+    pts = rays[..., None, :3] + rays[..., None, 3:6] * z_vals[..., :, None]
+    return pts.clamp(-(bound - 1e-6), bound - 1e-6)
+
+
+def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_noise_std, t_rand=None):
+    if not rays.is_cuda:
+        raise RuntimeError("render: rays must live on the GPU (no CPU path)")
+    rays = rays.contiguous().float()
+    n_rays = rays.shape[0]
+    if perturb and t_rand is None:
+        t_rand = torch.rand(n_rays, n_samples, device=rays.device)       # same RNG stream as render.py:99
+    if not perturb:
+        t_rand = None
+    fine = net_fine is not None and n_fine > 0
+    fused = (not fine) and raw_noise_std == 0.0 and getattr(net, "fused_supported", lambda: False)()
+
+    z_vals = pts = None
+    if RETURN_PTS or not fused:
+        z_vals, pts = _sample(rays, n_samples, perturb, net.bound, t_rand)
+    if fused:
+        acc = fused_render(rays, net, n_samples, perturb, t_rand=t_rand)
+        weights = None
+    else:
+        raw = run_network(pts, net, netchunk)
+        acc, weights = raw2outputs(raw, z_vals, rays[..., 3:6], raw_noise_std)
+
+    ret = {}
+    if fine:
+        ret.update(acc0=acc, weights0=weights, pts0=pts)
+        z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        z_samples = sample_pdf(z_mid, weights[..., 1:-1], n_fine, det=(perturb == 0.0)).detach()
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
+        pts = _points(rays, z_vals, net.bound)
+        raw = run_network(pts, net_fine, netchunk)
+        acc, _ = raw2outputs(raw, z_vals, rays[..., 3:6], raw_noise_std)
+    ret["acc"] = acc
+    if pts is not None:
+        ret["pts"] = pts
+        ret["tv_loss"] = torch.sum(torch.abs(pts[:, 1:, :] - pts[:, :-1, :])) * 0.1       # render.py:129-131
+    if CHECK_NUMERICS:
+        for k in ret:
+            if ret[k] is not None and not torch.isfinite(ret[k]).all():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def render(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_noise_std, chunk_size=None, t_rand=None):
+    n_rays = rays.shape[0]
+    if chunk_size is None or chunk_size >= n_rays:
+        return render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_noise_std, t_rand)
+    parts = []
+    for i in range(0, n_rays, chunk_size):
+        tr = None if t_rand is None else t_rand[i:i + chunk_size].contiguous()
+        parts.append(render_chunk(rays[i:i + chunk_size], net, net_fine, n_samples, n_fine, perturb, netchunk,
+                                  raw_noise_std, tr))
+    ret = {"acc": torch.cat([p["acc"] for p in parts], 0)}
+    if "pts" in parts[0]:
+        ret["pts"] = torch.cat([p["pts"] for p in parts], 0)
+    if "acc0" in parts[0]:
+        for k in ("acc0", "weights0", "pts0"):
+            ret[k] = torch.cat([p[k] for p in parts], 0)
+    return ret
