@@ -45,6 +45,12 @@ typedef enum naf_layout {
 const char *naf_last_error(void);
 int naf_abi_version(void);
 
+/* Optional per-kernel timing for bench.py: when enabled, every kernel launched through this library is bracketed
+ * by a pair of HIP events on ITS launch stream.  naf_profile_collect() synchronises them and writes one text line
+ * per kernel ("<kernel> <launches> <total_ms>\n") into `buf`, then clears the log.  Up to 8192 launches are kept. */
+int naf_profile_enable(int on);
+int naf_profile_collect(char *buf, size_t buflen);
+
 /* ------------------------------------------------------------------------------------------------
  * E6  hash_encode_forward   (replaces hashencoder.cu:373-396 / hashencoder.h:13)
  *   inputs      f32  [B, D]   in [0,1]
@@ -80,6 +86,15 @@ int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float
                     uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,
                     void *stream);
 
+/* G3/G4  ray generation (replaces the precomputed rays[N,H,W,8] of tigre.py:247-255,402-456,463-528)
+ *   poses   f32 [n_projections, 3, 4]  = [R | t] of angle2pose (tigre.py:530-572), cast to fp32 like torch.Tensor(pose)
+ *   pixels  i64 [n] flat pixel index  proj*H*W + row*W + col, or NULL for the dense range first_pixel .. first_pixel+n-1
+ *   rays    f32 [n, 8] out (16-byte aligned): origin, direction (cone: un-normalised, tigre.py:434-437), near, far
+ */
+int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,
+                      uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov,
+                      float DSD, float near, float far, int parallel, void *stream);
+
 /* R4  line integral acc = sum_s sigma_s * dist_s  (render.py:192-201), and its backward.
  *   sigma f32 [n_rays, S]; z_vals f32 [n_rays, S]; rays f32 [n_rays, 8]; acc f32 [n_rays]
  *   backward: grad_sigma[r,s] = grad_acc[r] * dist[r,s]
@@ -109,8 +124,17 @@ typedef struct naf_render_cfg {
     int32_t last_activation; /* 0 sigmoid, 1 leaky-relu, 2 tanh, 3 none (network.py:23-32)        */
     uint64_t seed;           /* jitter seed when t_rand == NULL                                   */
     uint32_t ray_index_base; /* global index of ray 0 of this call (jitter stream is per global ray) */
-    uint32_t reserved;
+    uint32_t log2_hashmap_size; /* hashgrid.py:81 (sizes the binned gradient scatter; 0 = unknown -> plain atomics) */
 } naf_render_cfg;
+
+/* How naf_render_backward / naf_render_train scatter the table gradient: 0 = auto (binned two-pass scatter from
+ * 2^17 points per call, plain fp32 atomics below), 1 = always atomics (the reference's scheme, hashencoder.cu:257-269),
+ * 2 = always binned.  Process-wide; call before naf_render_workspace_bytes (the workspace size depends on it). */
+int naf_set_scatter_mode(int mode);
+
+/* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
+ * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */
+int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host);
 
 /* Workspace size in bytes for naf_render_* / naf_field_forward over `n_points` points (= n_rays * n_samples for the
  * render entry points): feature and feature-gradient tensors [L, n_points, C] plus the MLP-gradient slabs. */

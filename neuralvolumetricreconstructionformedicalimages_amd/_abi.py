@@ -27,7 +27,7 @@ class RenderCfg(ctypes.Structure):
         ("n_samples", ctypes.c_uint32), ("perturb", ctypes.c_int32), ("bound", ctypes.c_float),
         ("L", ctypes.c_uint32), ("C", ctypes.c_uint32), ("H", ctypes.c_uint32),
         ("table_dtype", ctypes.c_int32), ("mlp_precision", ctypes.c_int32), ("last_activation", ctypes.c_int32),
-        ("seed", ctypes.c_uint64), ("ray_index_base", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("seed", ctypes.c_uint64), ("ray_index_base", ctypes.c_uint32), ("log2_hashmap_size", ctypes.c_uint32),
     ]
 
 
@@ -36,11 +36,16 @@ _vp, _u32, _u64, _i32, _f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64,
 SIGNATURES = {
     "naf_last_error": (ctypes.c_char_p, []),
     "naf_abi_version": (_i32, []),
+    "naf_profile_enable": (_i32, [_i32]),
+    "naf_profile_collect": (_i32, [ctypes.c_char_p, ctypes.c_size_t]),
     "naf_hash_encode_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _i32, _i32, _vp]),
     "naf_hash_encode_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "naf_sample_rays": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _f32, _u64, _u32, _vp]),
+    "naf_generate_rays": (_i32, [_vp, _vp, ctypes.c_int64, _vp, _u64, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "naf_integrate_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "naf_integrate_backward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "naf_set_scatter_mode": (_i32, [_i32]),
+    "naf_scatter_overflow_count": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32)]),
     "naf_render_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
     "naf_render_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _i32, _vp]),
@@ -98,3 +103,18 @@ def ptr(t):
 
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_enable(on=True):
+    check(lib().naf_profile_enable(int(on)), "profile_enable")
+
+
+def profile_collect():
+    """-> {kernel: (launches, total_ms)} for everything launched since profile_enable(True)."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().naf_profile_collect(buf, len(buf)), "profile_collect")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, count, ms = line.rsplit(" ", 2)
+        out[name] = (int(count), float(ms))
+    return out

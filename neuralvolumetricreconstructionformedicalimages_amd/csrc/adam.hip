@@ -81,9 +81,9 @@ extern "C" int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, fl
     a.bias2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n / 4 + 255) / 256, 256u * 16u));
     hipStream_t s = (hipStream_t)stream;
-    if (!param_lp) hipLaunchKernelGGL(adam_kernel<0>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, nullptr, n, a, zero_grad != 0);
-    else if (lp_dtype == NAF_F16) hipLaunchKernelGGL(adam_kernel<1>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0);
-    else if (lp_dtype == NAF_BF16) hipLaunchKernelGGL(adam_kernel<2>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0);
+    if (!param_lp) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<0>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, nullptr, n, a, zero_grad != 0); }
+    else if (lp_dtype == NAF_F16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<1>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0); }
+    else if (lp_dtype == NAF_BF16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<2>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0); }
     else return fail(NAF_ERR_UNSUPPORTED, "adam_step: lp_dtype must be NAF_F16 or NAF_BF16 when param_lp is given");
     return check_launch("adam_kernel");
 }

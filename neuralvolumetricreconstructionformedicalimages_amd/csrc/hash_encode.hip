@@ -32,8 +32,8 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_forward(const float *inputs, const void *emb, const int32_t *offsets, void *out, uint32_t B, uint32_t L,
                           uint32_t H, bool blc, void *dy_dx, hipStream_t s) {
     using S = typename T::store_t;
-    hipLaunchKernelGGL((hash_forward_kernel<T, D, C, SrcUnit<D>>), dim3(hash_grid_x(B), L), dim3(256), 0, s,
-                       SrcUnit<D>{inputs}, (const S *)emb, offsets, (S *)out, B, L, H, blc, (S *)dy_dx);
+    { ProfScope prof_("hash_forward_kernel", s); hipLaunchKernelGGL((hash_forward_kernel<T, D, C, SrcUnit<D>>), dim3(hash_grid_x(B), L), dim3(256), 0, s,
+                       SrcUnit<D>{inputs}, (const S *)emb, offsets, (S *)out, B, L, H, blc, (S *)dy_dx); }
     return check_launch("hash_forward_kernel");
 }
 
@@ -41,12 +41,12 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_backward(const void *grad, const float *inputs, const int32_t *offsets, float *gtab, uint32_t B,
                            uint32_t L, uint32_t H, bool blc, const void *dy_dx, float *ginp, hipStream_t s) {
     using S = typename T::store_t;
-    hipLaunchKernelGGL((hash_backward_kernel<T, D, C, SrcUnit<D>>), dim3(hash_grid_x(B), L), dim3(256), 0, s,
-                       SrcUnit<D>{inputs}, (const S *)grad, offsets, gtab, B, L, H, blc);
+    { ProfScope prof_("hash_backward_kernel", s); hipLaunchKernelGGL((hash_backward_kernel<T, D, C, SrcUnit<D>>), dim3(hash_grid_x(B), L), dim3(256), 0, s,
+                       SrcUnit<D>{inputs}, (const S *)grad, offsets, gtab, B, L, H, blc); }
     int rc = check_launch("hash_backward_kernel");
     if (rc != NAF_OK || dy_dx == nullptr) return rc;
-    hipLaunchKernelGGL((input_backward_kernel<T, D, C>), dim3(((uint64_t)B * D + 255) / 256), dim3(256), 0, s,
-                       (const S *)grad, (const S *)dy_dx, ginp, B, L, blc);
+    { ProfScope prof_("input_backward_kernel", s); hipLaunchKernelGGL((input_backward_kernel<T, D, C>), dim3(((uint64_t)B * D + 255) / 256), dim3(256), 0, s,
+                       (const S *)grad, (const S *)dy_dx, ginp, B, L, blc); }
     return check_launch("input_backward_kernel");
 }
 

@@ -15,6 +15,8 @@
 //   * [L,B,C] features are written as fully coalesced C*sizeof(T)*64-byte rows per wave.
 #pragma once
 
+#include <cstdlib>
+
 #include "naf_device.h"
 
 namespace naf {
@@ -56,6 +58,11 @@ struct SrcRays {
         if (perturb) u = t_rand ? t_rand[(size_t)r * S + s] : jitter(seed, ray_base + r, s);
         return sample_z(near, far, s, S, perturb, u);
     }
+    // distance between consecutive samples of the first ray in [0,1] coordinates (for locality heuristics only)
+    __device__ __forceinline__ float sample_spacing() const {
+        const float dn = sqrtf(rays[3] * rays[3] + rays[4] * rays[4] + rays[5] * rays[5]);
+        return (rays[7] - rays[6]) * dn / ((float)S * 2.0f * bound);
+    }
     __device__ __forceinline__ void get(uint32_t b, float (&out)[3]) const {
         const uint32_t r = b / S, s = b - r * S;
         const float *ray = rays + (size_t)r * 8;
@@ -75,12 +82,14 @@ template <typename T, uint32_t D, uint32_t C, typename Src>
 __global__ void __launch_bounds__(256)
 hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
                     typename T::store_t *__restrict__ outputs, uint32_t B, uint32_t L, uint32_t H, bool blc_layout,
-                    typename T::store_t *__restrict__ dy_dx) {
+                    typename T::store_t *__restrict__ dy_dx, uint32_t level_base = 0) {
     using S = typename T::store_t;
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = level_base + blockIdx.y;
     const LevelMeta m = make_level_meta<D>(offsets, level, H);
     const S *__restrict__ grid = table + (size_t)m.offset * C;
 
+    dispatch_mode(m.mode, [&](auto mode_tag) {
+    constexpr uint32_t MODE = decltype(mode_tag)::value;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         float x[D];
         src.get(b, x);
@@ -94,7 +103,7 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
         for (uint32_t c = 0; c < (1u << D); ++c) {
             uint32_t pl[D];
             w[c] = corner<D>(c, frac, pg, pl);
-            load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, v[c]);
+            load_vec<T, C>(grid + (size_t)grid_row<MODE, D>(m, pl) * C, v[c]);
         }
         float acc[C];
 #pragma unroll
@@ -126,9 +135,9 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
                     }
                     float lo[C], hi[C];
                     pl[gd] = pg[gd];
-                    load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, lo);
+                    load_vec<T, C>(grid + (size_t)grid_row<MODE, D>(m, pl) * C, lo);
                     pl[gd] = pg[gd] + 1u;
-                    load_vec<T, C>(grid + (size_t)grid_row<D>(m, pl) * C, hi);
+                    load_vec<T, C>(grid + (size_t)grid_row<MODE, D>(m, pl) * C, hi);
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) g[ch] = __fmaf_rn(wc, hi[ch] - lo[ch], g[ch]);
                 }
@@ -136,6 +145,7 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
             }
         }
     }
+    });
 }
 
 // ---- backward -----------------------------------------------------------------------------------------
@@ -144,11 +154,14 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
 template <typename T, uint32_t D, uint32_t C, typename Src>
 __global__ void __launch_bounds__(256)
 hash_backward_kernel(Src src, const typename T::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
-                     float *__restrict__ grad_table, uint32_t B, uint32_t L, uint32_t H, bool blc_layout) {
-    const uint32_t level = blockIdx.y;
+                     float *__restrict__ grad_table, uint32_t B, uint32_t L, uint32_t H, bool blc_layout,
+                     uint32_t level_base = 0) {
+    const uint32_t level = level_base + blockIdx.y;
     const LevelMeta m = make_level_meta<D>(offsets, level, H);
     float *__restrict__ gg = grad_table + (size_t)m.offset * C;
 
+    dispatch_mode(m.mode, [&](auto mode_tag) {
+    constexpr uint32_t MODE = decltype(mode_tag)::value;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         float x[D];
         src.get(b, x);
@@ -161,12 +174,24 @@ hash_backward_kernel(Src src, const typename T::store_t *__restrict__ grad, cons
         for (uint32_t c = 0; c < (1u << D); ++c) {
             uint32_t pl[D];
             const float w = corner<D>(c, frac, pg, pl);
-            float *dst = gg + (size_t)grid_row<D>(m, pl) * C;
+            float *dst = gg + (size_t)grid_row<MODE, D>(m, pl) * C;
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(dst + ch, w * g[ch]);
         }
     }
+    });
 }
+
+// NAF_PROFILE_LEVELS=1 splits the level-major launches into one launch per level so that
+// naf_profile_collect() reports a per-level time (diagnostics only).
+static inline bool profile_levels() {
+    static const bool on = [] { const char *e = std::getenv("NAF_PROFILE_LEVELS"); return e && e[0] == '1'; }();
+    return on;
+}
+static inline const char *level_name(const char *const (&names)[32], uint32_t l) { return names[l < 32 ? l : 31]; }
+#define NAF_LEVEL_NAMES(P) { P "00", P "01", P "02", P "03", P "04", P "05", P "06", P "07", P "08", P "09", P "10", P "11", \
+                             P "12", P "13", P "14", P "15", P "16", P "17", P "18", P "19", P "20", P "21", P "22", P "23", \
+                             P "24", P "25", P "26", P "27", P "28", P "29", P "30", P "31" }
 
 static inline uint32_t hash_grid_x(uint32_t B) {
     return (uint32_t)std::min<uint64_t>(((uint64_t)B + 255) / 256, 1u << 20);

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace naf {
 
 constexpr uint32_t kPrime1 = 19349663u;
@@ -65,11 +67,11 @@ __device__ __forceinline__ LevelMeta make_level_meta(const int32_t *__restrict__
     return m;
 }
 
-// hashencoder.cu:55-74 with the level regime pre-decoded.  Returns the row (not multiplied by C).
-template <uint32_t D>
+// hashencoder.cu:55-74 with the level regime as a compile-time constant.  Returns the row (not multiplied by C).
+template <uint32_t MODE, uint32_t D>
 __device__ __forceinline__ uint32_t grid_row(const LevelMeta &m, const uint32_t (&p)[D]) {
     uint32_t idx;
-    if (m.mode >= kHashMask) {
+    if constexpr (MODE >= kHashMask) {
         idx = p[0];                         // prime 1
         idx ^= p[1] * kPrime1;
         if constexpr (D > 2) idx ^= p[2] * kPrime2;
@@ -77,9 +79,22 @@ __device__ __forceinline__ uint32_t grid_row(const LevelMeta &m, const uint32_t 
         idx = p[0] + p[1] * m.stride1;
         if constexpr (D > 2) idx += p[2] * m.stride2;
     }
-    if (m.mode == kDenseMask || m.mode == kHashMask) idx &= (m.size - 1u);
-    else if (m.mode != kDenseNoMod) idx %= m.size;
+    if constexpr (MODE == kDenseMask || MODE == kHashMask) idx &= (m.size - 1u);
+    else if constexpr (MODE != kDenseNoMod) idx %= m.size;
     return idx;
+}
+
+// Runs `body(std::integral_constant<uint32_t, MODE>{})` for the (wave-uniform) regime of the level: one scalar
+// branch per kernel instead of one per corner, and straight-line gather code inside.
+template <typename Body>
+__device__ __forceinline__ void dispatch_mode(uint32_t mode, Body &&body) {
+    switch (mode) {
+        case kDenseNoMod: body(std::integral_constant<uint32_t, kDenseNoMod>{}); break;
+        case kDenseMask:  body(std::integral_constant<uint32_t, kDenseMask>{}); break;
+        case kDenseMod:   body(std::integral_constant<uint32_t, kDenseMod>{}); break;
+        case kHashMask:   body(std::integral_constant<uint32_t, kHashMask>{}); break;
+        default:          body(std::integral_constant<uint32_t, kHashMod>{}); break;
+    }
 }
 
 // hashencoder.cu:106-111.  nvcc contracts x*scale+0.5 into an FMA; we ask for it explicitly.
@@ -181,13 +196,18 @@ __device__ __forceinline__ void store_vec(typename T::store_t *p, const float (&
 }
 
 // ---- counter-based jitter (used when the caller passes no t_rand) --------------------------------
-// splitmix64-style finaliser over (seed, global ray index, sample); 24 random bits -> [0,1).
+// Two rounds of the "lowbias32" integer finaliser over (seed, global ray index, sample); 24 bits -> [0,1).
+// 32-bit only on purpose: it is re-evaluated by every kernel that needs the sample position.
+__device__ __host__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du;
+    h ^= h >> 15; h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
+}
 __device__ __host__ __forceinline__ float jitter(uint64_t seed, uint32_t ray, uint32_t sample) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((((uint64_t)ray) << 32) | (uint64_t)sample) + 0x632BE59BD9B4E019ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+    uint32_t h = mix32((uint32_t)seed ^ (ray * 0x9e3779b1u));
+    h = mix32(h ^ (uint32_t)(seed >> 32) ^ (sample * 0x85ebca77u) ^ 0x27d4eb2fu);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
 // ---- stratified depth of sample s on a ray (render.py:87-100) ------------------------------------

@@ -12,10 +12,12 @@
 //   4 hash_backward_kernel<SrcRays>  dfeat -> grad table (fp32 atomics)
 //   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=)
 #include <algorithm>
+#include <cstring>
 
 #include "naf_host.h"
 #include "hash_kernels.h"
 #include "field_mlp.h"
+#include "scatter_binned.h"
 
 namespace naf {
 
@@ -325,8 +327,45 @@ static uint32_t backward_lds_bytes() {
 struct Workspace {
     unsigned char *feat, *dfeat;
     float *slabs, *grad_acc;
+    unsigned char *regions;      // binned scatter: per-(level, bucket) record streams
+    uint32_t *counts;            //                 stream cursors
+    uint32_t *overflow;          //                 contributions that fell back to atomics (diagnostic counter)
+    BinPlan plan;
+    bool binned;
     size_t bytes;
 };
+
+constexpr uint64_t kBinMinPoints = 1u << 17;             // below this the plain atomic kernel is launch-bound anyway
+constexpr size_t kBinBudgetBytes = (size_t)6 << 30;      // stream buffer per pass; more levels per pass = fewer launches
+
+static size_t record_bytes(const naf_render_cfg *cfg) {
+    return cfg->mlp_precision == NAF_F32 ? 4u * (1u + cfg->C) : 4u * (1u + (cfg->C + 1u) / 2u);
+}
+
+static int g_scatter_mode = 0;      // naf_set_scatter_mode: 0 auto, 1 always atomics, 2 always binned
+
+static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan *plan) {
+    if (g_scatter_mode == 1 || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
+    if (g_scatter_mode == 0 && n_points < kBinMinPoints) return false;
+    const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
+    uint32_t log2_nb = 8;
+    while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (double) must fit LDS
+    // pass-1 tile: its 8 records per point are counting-sorted in LDS (<= 64 KiB of staging); 256 threads x PPT points
+    const uint32_t ppt = record_bytes(cfg) <= 8 ? 4u : record_bytes(cfg) <= 16 ? 2u : 1u;
+    const uint32_t tile = 256u * ppt;
+    plan->tile_points = tile;
+    plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
+    plan->log2_nb = log2_nb;
+    // sub-streams keep the reservation cursors from becoming hot spots (one returning atomic per tile and bucket)
+    plan->log2_sub = plan->n_tiles >= 1024 ? 4u : plan->n_tiles >= 64 ? 2u : 0u;
+    const uint64_t mean = ((n_points * 8u) >> log2_nb) >> plan->log2_sub;
+    plan->stream_cap = (uint32_t)std::min<uint64_t>(mean + mean / 4 + 1024u, 0xffffffffu);
+    plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
+    const size_t per_level = (((size_t)plan->stream_cap << log2_nb) << plan->log2_sub) * record_bytes(cfg);
+    plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
+    if (profile_levels()) plan->levels_per_pass = 1;
+    return true;
+}
 static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points) {
     const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
     const size_t feat_bytes = ((size_t)n_points * cfg->L * cfg->C * esz + 255) & ~(size_t)255;
@@ -338,6 +377,18 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
     w.slabs = (float *)(w.dfeat + feat_bytes);
     w.grad_acc = (float *)((unsigned char *)w.slabs + slab_bytes);
     w.bytes = 2 * feat_bytes + slab_bytes + ((n_rays_max * 4 + 255) & ~(size_t)255);
+    w.binned = make_bin_plan(cfg, n_points, &w.plan);
+    w.regions = nullptr;
+    w.counts = nullptr;
+    w.overflow = nullptr;
+    if (w.binned) {
+        const size_t n_streams = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) << w.plan.log2_sub;
+        const size_t stream_bytes = (n_streams * w.plan.stream_cap * record_bytes(cfg) + 255) & ~(size_t)255;
+        w.regions = (unsigned char *)base + w.bytes;
+        w.counts = (uint32_t *)(w.regions + stream_bytes);
+        w.overflow = w.counts + n_streams;
+        w.bytes += stream_bytes + (((n_streams + 1) * 4 + 255) & ~(size_t)255);
+    }
     return w;
 }
 
@@ -361,10 +412,12 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
 template <typename TT, typename FT, uint32_t C, typename Src>
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H) {
-    const uint32_t level = blockIdx.y;
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base) {
+    const uint32_t level = level_base + blockIdx.y;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
+    dispatch_mode(m.mode, [&](auto mode_tag) {
+    constexpr uint32_t MODE = decltype(mode_tag)::value;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         float x[3];
         src.get(b, x);
@@ -376,7 +429,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
         for (uint32_t c = 0; c < 8; ++c) {
             uint32_t pl[3];
             w[c] = corner<3>(c, frac, pg, pl);
-            load_vec<TT, C>(grid + (size_t)grid_row<3>(m, pl) * C, v[c]);
+            load_vec<TT, C>(grid + (size_t)grid_row<MODE, 3>(m, pl) * C, v[c]);
         }
         float a[C];
 #pragma unroll
@@ -387,13 +440,23 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
             for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[c], v[c][ch], a[ch]);
         store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
     }
+    });
 }
 
 template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
     using FT = typename P::feat_t;
-    hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H);
+    if (profile_levels()) {
+        static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
+        for (uint32_t l = 0; l < cfg->L; ++l) {
+            ProfScope prof_(level_name(names, l), s);
+            hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x(B), 1), dim3(256), 0, s, src,
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l);
+        }
+        return check_launch("encode_kernel");
+    }
+    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u); }
     return check_launch("encode_kernel");
 }
 
@@ -413,8 +476,8 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     const uint32_t lds = forward_lds_bytes<P>();
     const uint64_t waves_needed = kRays ? n_items : ((uint64_t)n_items + 31) / 32;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, 256u * 8u));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, n_items, B,
-                       cfg->last_activation);
+    { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, n_items, B,
+                       cfg->last_activation); }
     return check_launch("mlp_forward_kernel");
 }
 
@@ -430,19 +493,69 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
         attr_set = true;
     }
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
-                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation);
+    { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
+                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
-    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + 255) / 256), dim3(256), 0, s, slabs, grid, grad_mlp);
+    { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + 255) / 256), dim3(256), 0, s, slabs, grid, grad_mlp); }
     return check_launch("mlp_grad_reduce_kernel");
+}
+
+template <typename P, uint32_t C, typename Rec>
+static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                              const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+    using FT = typename P::feat_t;
+    constexpr uint32_t PPT = sizeof(Rec) <= 8 ? 4u : sizeof(Rec) <= 16 ? 2u : 1u;      // must match make_bin_plan
+    auto bin = scatter_bin_kernel<FT, C, SrcRays, Rec, PPT>;
+    auto red = scatter_reduce_kernel<C, Rec>;
+    const BinPlan &plan = w.plan;
+    const uint32_t NB = 1u << plan.log2_nb;
+    const uint32_t red_lds = plan.max_local_rows * C * 8u;
+    const uint32_t bin_lds = (3u * NB + 4u) * 4u + plan.tile_points * 8u * (uint32_t)sizeof(Rec);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)red, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(red_lds, 64u << 10)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)bin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(bin_lds, 64u << 10)) != hipSuccess)
+            return fail(NAF_ERR_LAUNCH, "binned scatter: cannot raise dynamic LDS limit");
+        attr_set = true;
+    }
+    if (hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
+    for (uint32_t l0 = 0; l0 < cfg->L; l0 += plan.levels_per_pass) {
+        const uint32_t nl = std::min(plan.levels_per_pass, cfg->L - l0);
+        if (hipMemsetAsync(w.counts, 0, ((size_t)nl * NB * 4u) << plan.log2_sub, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
+        static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
+        static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
+        const bool per_level = profile_levels();
+        { ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
+          hipLaunchKernelGGL(bin, dim3(plan.n_tiles, nl), dim3(256), bin_lds, s, src, (const typename FT::store_t *)dfeat,
+                             offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, plan); }
+        if (int rc = check_launch("scatter_bin_kernel")) return rc;
+        { ProfScope prof_(per_level ? level_name(red_names, l0) : "scatter_reduce_kernel", s);
+          hipLaunchKernelGGL(red, dim3(NB, nl), dim3(256), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
+                             grad_table, l0, plan); }
+        if (int rc = check_launch("scatter_reduce_kernel")) return rc;
+    }
+    return NAF_OK;
 }
 
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                             const naf_render_cfg *cfg, hipStream_t s) {
+                             const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
     using FT = typename P::feat_t;
-    hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
-                       (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false);
+    if (w.binned) {
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+    }
+    if (profile_levels()) {
+        static const char *const names[32] = NAF_LEVEL_NAMES("hash_backward_kernel_L");
+        for (uint32_t l = 0; l < cfg->L; ++l) {
+            ProfScope prof_(level_name(names, l), s);
+            hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), 1), dim3(256), 0, s, src,
+                               (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false, l);
+        }
+        return check_launch("hash_backward_kernel");
+    }
+    { ProfScope prof_("hash_backward_kernel", s); hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
+                       (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false, 0u); }
     return check_launch("hash_backward_kernel");
 }
 
@@ -473,7 +586,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     if (!features_valid)
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
     if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, grad_mlp, n_rays, B, cfg, s)) return rc;
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, s);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, s);
 }
 
 template <typename P, uint32_t C>
@@ -482,7 +595,7 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
     const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(1), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, n_rays);
+    { ProfScope prof_("loss_grad_kernel", s); hipLaunchKernelGGL(loss_grad_kernel, dim3(1), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, n_rays); }
     if (int rc = check_launch("loss_grad_kernel")) return rc;
     return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, s);
 }
@@ -518,6 +631,21 @@ static int field_forward_impl(const float *pts, const void *emb, const int32_t *
 }  // namespace naf
 
 using namespace naf;
+
+extern "C" int naf_set_scatter_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(NAF_ERR_INVALID_ARGUMENT, "set_scatter_mode: mode must be 0 (auto), 1 (atomic) or 2 (binned)");
+    g_scatter_mode = mode;
+    return NAF_OK;
+}
+
+extern "C" int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host) {
+    if (!cfg || !workspace || !count_host) return fail(NAF_ERR_INVALID_ARGUMENT, "scatter_overflow_count: null pointer");
+    const Workspace w = carve(const_cast<void *>(workspace), cfg, n_points);
+    *count_host = 0;
+    if (!w.binned) return NAF_OK;
+    if (hipMemcpy(count_host, w.overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(NAF_ERR_LAUNCH, "scatter_overflow_count: copy failed");
+    return NAF_OK;
+}
 
 extern "C" size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
     if (!cfg) return 0;

@@ -117,8 +117,8 @@ extern "C" int naf_sample_rays(const float *rays, const float *t_rand, float *z_
     if (n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: n_samples must be >= 2");
     if (n_rays == 0) return NAF_OK;
     const uint64_t total = (uint64_t)n_rays * n_samples;
-    hipLaunchKernelGGL(sample_rays_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, rays, t_rand,
-                       z_vals, pts, n_rays, n_samples, perturb != 0, bound, seed, ray_index_base);
+    { ProfScope prof_("sample_rays_kernel", (hipStream_t)stream); hipLaunchKernelGGL(sample_rays_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, rays, t_rand,
+                       z_vals, pts, n_rays, n_samples, perturb != 0, bound, seed, ray_index_base); }
     return check_launch("sample_rays_kernel");
 }
 
@@ -126,8 +126,8 @@ extern "C" int naf_integrate_forward(const float *sigma, const float *z_vals, co
                                      uint32_t n_rays, uint32_t n_samples, void *stream) {
     if (!sigma || !z_vals || !rays || !acc) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_forward: null pointer");
     if (n_rays == 0) return NAF_OK;
-    hipLaunchKernelGGL(integrate_forward_kernel, dim3(grid_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
-                       z_vals, rays, acc, n_rays, n_samples);
+    { ProfScope prof_("integrate_forward_kernel", (hipStream_t)stream); hipLaunchKernelGGL(integrate_forward_kernel, dim3(grid_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
+                       z_vals, rays, acc, n_rays, n_samples); }
     return check_launch("integrate_forward_kernel");
 }
 
@@ -136,15 +136,80 @@ extern "C" int naf_integrate_backward(const float *grad_acc, const float *z_vals
     if (!grad_acc || !z_vals || !rays || !grad_sigma) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_backward: null pointer");
     if (n_rays == 0) return NAF_OK;
     const uint64_t total = (uint64_t)n_rays * n_samples;
-    hipLaunchKernelGGL(integrate_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       grad_acc, z_vals, rays, grad_sigma, n_rays, n_samples);
+    { ProfScope prof_("integrate_backward_kernel", (hipStream_t)stream); hipLaunchKernelGGL(integrate_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_acc, z_vals, rays, grad_sigma, n_rays, n_samples); }
     return check_launch("integrate_backward_kernel");
 }
 
 extern "C" int naf_normalize_inputs(const float *x, uint64_t n, float size, float *out01, int32_t *flag, void *stream) {
     if (!x || !flag) return fail(NAF_ERR_INVALID_ARGUMENT, "normalize_inputs: null pointer");
     if (n == 0) return NAF_OK;
-    hipLaunchKernelGGL(normalize_inputs_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x, n,
-                       size, out01, flag);
+    { ProfScope prof_("normalize_inputs_kernel", (hipStream_t)stream); hipLaunchKernelGGL(normalize_inputs_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       size, out01, flag); }
     return check_launch("normalize_inputs_kernel");
+}
+
+// ---- G3/G4: on-the-fly ray generation (reference src/dataset/tigre.py:402-456, 463-528) --------------------------
+// The reference precomputes rays[N,H,W,8] for every pixel of every projection (419 MB at 50x512^2, 24 GB at
+// 720x1024^2); here a ray is 32 bytes produced on demand from its pose and pixel.
+namespace naf {
+
+struct RayGeo {
+    uint32_t W, H;          // detector columns / rows (nDetector[0], nDetector[1])
+    float du, dv;           // pixel pitch  (dDetector)
+    float ou, ov;           // detector offset (offDetector)
+    float DSD;
+    float near, far;        // tigre.py:575-586
+    int parallel;           // 0 cone, 1 parallel
+};
+
+__global__ void __launch_bounds__(256)
+generate_rays_kernel(const float *__restrict__ poses, const int64_t *__restrict__ pixels, int64_t first_pixel,
+                     float *__restrict__ rays, uint64_t n, RayGeo g) {
+    const uint64_t per_proj = (uint64_t)g.W * g.H;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t flat = pixels ? (uint64_t)pixels[i] : (uint64_t)first_pixel + i;
+        const uint32_t proj = (uint32_t)(flat / per_proj);
+        const uint32_t rem = (uint32_t)(flat - (uint64_t)proj * per_proj);
+        const uint32_t row = rem / g.W, col = rem - row * g.W;
+        const float *P = poses + (size_t)proj * 12;                 // 3x4 row-major [R | t]
+        // tigre.py:423-429: uu along columns, vv along rows
+        const float uu = ((float)col + 0.5f - (float)g.W / 2.0f) * g.du + g.ou;
+        const float vv = ((float)row + 0.5f - (float)g.H / 2.0f) * g.dv + g.ov;
+        float o[3], d[3];
+        if (!g.parallel) {                                          // tigre.py:434-437
+            const float dx = uu / g.DSD, dy = vv / g.DSD;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = P[4 * k + 0] * dx + P[4 * k + 1] * dy + P[4 * k + 2];
+                o[k] = P[4 * k + 3];
+            }
+        } else {                                                    // tigre.py:438-447
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = P[4 * k + 2];
+                o[k] = P[4 * k + 0] * uu + P[4 * k + 1] * vv + P[4 * k + 3];
+            }
+        }
+        float4 *out = reinterpret_cast<float4 *>(rays + i * 8);
+        out[0] = make_float4(o[0], o[1], o[2], d[0]);
+        out[1] = make_float4(d[1], d[2], g.near, g.far);
+    }
+}
+
+}  // namespace naf
+
+extern "C" int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,
+                                 uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv, float ou,
+                                 float ov, float DSD, float near, float far, int parallel, void *stream) {
+    if (!poses || !rays) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: null pointer");
+    if (det_w == 0 || det_h == 0 || n_projections == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: empty detector");
+    if (((uintptr_t)rays) & 15u) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: rays must be 16-byte aligned");
+    if (!pixels && (first_pixel < 0 || (uint64_t)first_pixel + n > (uint64_t)n_projections * det_w * det_h))
+        return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: pixel range outside the scan");
+    if (n == 0) return NAF_OK;
+    RayGeo g{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
+    { ProfScope prof_("generate_rays_kernel", (hipStream_t)stream); hipLaunchKernelGGL(generate_rays_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, poses, pixels,
+                       first_pixel, rays, n, g); }
+    return check_launch("generate_rays_kernel");
 }

@@ -31,7 +31,7 @@ def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_ba
     return _abi.RenderCfg(n_samples=int(n_samples), perturb=int(bool(perturb)), bound=float(net.bound),
                           L=enc.num_levels, C=enc.level_dim, H=enc.base_resolution, table_dtype=table_dtype,
                           mlp_precision=int(mlp_precision), last_activation=LAST_ACTIVATIONS[net.last_activation],
-                          seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), reserved=0)
+                          seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), log2_hashmap_size=int(enc.log2_hashmap_size))
 
 
 def workspace(cfg, n_points, device):
