@@ -351,7 +351,7 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     uint32_t log2_nb = 8;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (double) must fit LDS
     // pass-1 tile: its 8 records per point are counting-sorted in LDS (<= 64 KiB of staging); 256 threads x PPT points
-    const uint32_t ppt = record_bytes(cfg) <= 8 ? 4u : record_bytes(cfg) <= 16 ? 2u : 1u;
+    const uint32_t ppt = record_bytes(cfg) <= 16 ? 2u : 1u;
     const uint32_t tile = 256u * ppt;
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
@@ -504,7 +504,7 @@ template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                               const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
     using FT = typename P::feat_t;
-    constexpr uint32_t PPT = sizeof(Rec) <= 8 ? 4u : sizeof(Rec) <= 16 ? 2u : 1u;      // must match make_bin_plan
+    constexpr uint32_t PPT = sizeof(Rec) <= 16 ? 2u : 1u;      // must match make_bin_plan
     auto bin = scatter_bin_kernel<FT, C, SrcRays, Rec, PPT>;
     auto red = scatter_reduce_kernel<C, Rec>;
     const BinPlan &plan = w.plan;

@@ -110,6 +110,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     // A: rows + weights of this thread's contributions; count per bucket
     uint32_t row[PPT][8];
     float val[PPT][8][C];
+    uint64_t cell[PPT];
     const uint32_t lane = threadIdx.x & 63u;
     dispatch_mode(m.mode, [&](auto mode_tag) {
         constexpr uint32_t MODE = decltype(mode_tag)::value;
@@ -122,6 +123,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
             src.get(valid ? b : B - 1u, x);
             locate<3>(x, m.scale, frac, pg);
             load_vec<FT, C>(grad + ((size_t)level * B + (valid ? b : B - 1u)) * C, g);
+            cell[k] = valid ? ((uint64_t)pg[0] | ((uint64_t)pg[1] << 21) | ((uint64_t)pg[2] << 42)) : ~0ull;
 #pragma unroll
             for (uint32_t c = 0; c < 8; ++c) {
                 uint32_t pl[3];
@@ -130,32 +132,33 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ++ch) val[k][c][ch] = w * g[ch];
             }
-            if (dedup) {
-                // Consecutive samples of a ray that fall into the same cell hit the same 8 rows: merge each run of
-                // equal cells inside the wave (segmented inclusive scan), only the last lane of a run emits records.
-                const uint64_t cell = valid ? ((uint64_t)pg[0] | ((uint64_t)pg[1] << 21) | ((uint64_t)pg[2] << 42)) : ~0ull;
-                const uint64_t prev = __shfl_up(cell, 1, 64);
-                const uint64_t heads = __ballot(lane == 0u || cell != prev);
-                const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
-#pragma unroll
-                for (uint32_t d = 1; d < 64; d <<= 1) {
-                    const bool take = lane >= start + d;
-#pragma unroll
-                    for (uint32_t c = 0; c < 8; ++c)
-#pragma unroll
-                        for (uint32_t ch = 0; ch < C; ++ch) {
-                            const float t = __shfl_up(val[k][c][ch], d, 64);
-                            if (take) val[k][c][ch] += t;
-                        }
-                }
-                const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
-                if (!tail) {
-#pragma unroll
-                    for (uint32_t c = 0; c < 8; ++c) row[k][c] = 0xffffffffu;
-                }
-            }
         }
     });
+    if (dedup) {
+        // Consecutive samples of a ray that fall into the same cell hit the same 8 rows: merge each run of equal
+        // cells inside the wave (segmented inclusive scan); only the last lane of a run emits records.
+        for (uint32_t k = 0; k < PPT; ++k) {
+            const uint64_t prev = __shfl_up(cell[k], 1, 64);
+            const uint64_t heads = __ballot(lane == 0u || cell[k] != prev);
+            const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const bool take = lane >= start + d;
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c)
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) {
+                        const float t = __shfl_up(val[k][c][ch], d, 64);
+                        if (take) val[k][c][ch] += t;
+                    }
+            }
+            const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+            if (!tail) {
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c) row[k][c] = 0xffffffffu;
+            }
+        }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k)
 #pragma unroll
