@@ -126,7 +126,7 @@ template <typename P, uint32_t C>
 __global__ void __launch_bounds__(256)
 mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                     const float *__restrict__ grad_acc, typename P::feat_t::store_t *__restrict__ dfeat,
-                    float *__restrict__ slabs, uint32_t n_rays, uint32_t B, int act) {
+                    float *__restrict__ slabs, uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act) {
     using Sh = MlpShared<P>;
     using TR = typename P::tr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -142,6 +142,7 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
     // weight-gradient accumulators: lane (c,h), register t  <->  dW[out = slot_row(t,h)][in = c]
     f32x16 dW0 = {0}, dW1 = {0}, dW2a = {0}, dW2b = {0};
     float db0 = 0.0f, db1 = 0.0f, db2 = 0.0f, db3 = 0.0f;
+    float dmax = 0.0f;                                       // max |feature gradient| (scale of the binned scatter)
     float dw3[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) dw3[t] = 0.0f;
@@ -229,10 +230,16 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             if (valid) {
                 float o[16];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) o[t] = dx0[t];
+                for (int t = 0; t < 16; ++t) { o[t] = dx0[t]; dmax = fmaxf(dmax, fabsf(o[t])); }
                 store_feat_slots<typename P::feat_t, C>(dfeat, B, p, h, o);
             }
         }
+    }
+
+    if (gmax_bits != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if (lane == 0 && dmax > 0.0f) atomicMax(gmax_bits, __float_as_uint(dmax));      // positive floats order like uints
     }
 
     // ---- fold the 4 waves of the workgroup into one slab (fixed order -> deterministic), then one store ------
@@ -327,9 +334,10 @@ static uint32_t backward_lds_bytes() {
 struct Workspace {
     unsigned char *feat, *dfeat;
     float *slabs, *grad_acc;
-    unsigned char *regions;      // binned scatter: per-(level, bucket) record streams
-    uint32_t *counts;            //                 stream cursors
+    unsigned char *regions;      // binned scatter: record regions [level][bucket][tile][slot_cap]
+    uint32_t *counts;            //                 records per region
     uint32_t *overflow;          //                 contributions that fell back to atomics (diagnostic counter)
+    uint32_t *gmax;              //                 bit pattern of max |feature gradient| of the step (fixed-point scale)
     BinPlan plan;
     bool binned;
     size_t bytes;
@@ -348,20 +356,18 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     if (g_scatter_mode == 1 || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
     if (g_scatter_mode == 0 && n_points < kBinMinPoints) return false;
     const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
-    uint32_t log2_nb = 8;
-    while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (double) must fit LDS
-    // pass-1 tile: its 8 records per point are counting-sorted in LDS (<= 64 KiB of staging); 256 threads x PPT points
-    const uint32_t ppt = record_bytes(cfg) <= 16 ? 2u : 1u;
+    uint32_t log2_nb = 6;
+    while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
+    // pass-1 tile: 256 threads x PPT points; its records wait in LDS slots [bucket][slot_cap]
+    const uint32_t ppt = record_bytes(cfg) <= 8 ? 2u : 1u;
     const uint32_t tile = 256u * ppt;
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
-    // sub-streams keep the reservation cursors from becoming hot spots (one returning atomic per tile and bucket)
-    plan->log2_sub = plan->n_tiles >= 1024 ? 4u : plan->n_tiles >= 64 ? 2u : 0u;
-    const uint64_t mean = ((n_points * 8u) >> log2_nb) >> plan->log2_sub;
-    plan->stream_cap = (uint32_t)std::min<uint64_t>(mean + mean / 4 + 1024u, 0xffffffffu);
+    const uint32_t slot_mean = std::max<uint32_t>(1u, (tile * 8u) >> log2_nb);
+    plan->slot_cap = slot_mean + slot_mean / 2u + 8u;                           // Poisson tail beyond this is < 1e-4
     plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
-    const size_t per_level = (((size_t)plan->stream_cap << log2_nb) << plan->log2_sub) * record_bytes(cfg);
+    const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
     if (profile_levels()) plan->levels_per_pass = 1;
     return true;
@@ -381,13 +387,15 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
     w.regions = nullptr;
     w.counts = nullptr;
     w.overflow = nullptr;
+    w.gmax = nullptr;
     if (w.binned) {
-        const size_t n_streams = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) << w.plan.log2_sub;
-        const size_t stream_bytes = (n_streams * w.plan.stream_cap * record_bytes(cfg) + 255) & ~(size_t)255;
+        const size_t n_streams = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * w.plan.n_tiles;     // regions
+        const size_t stream_bytes = (n_streams * w.plan.slot_cap * record_bytes(cfg) + 255) & ~(size_t)255;
         w.regions = (unsigned char *)base + w.bytes;
         w.counts = (uint32_t *)(w.regions + stream_bytes);
         w.overflow = w.counts + n_streams;
-        w.bytes += stream_bytes + (((n_streams + 1) * 4 + 255) & ~(size_t)255);
+        w.gmax = w.overflow + 1;
+        w.bytes += stream_bytes + (((n_streams + 2) * 4 + 255) & ~(size_t)255);
     }
     return w;
 }
@@ -483,7 +491,8 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
 
 template <typename P, uint32_t C>
 static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, void *dfeat,
-                            float *slabs, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+                            float *slabs, uint32_t *gmax_bits, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg,
+                            hipStream_t s) {
     auto kern = mlp_backward_kernel<P, C>;
     const uint32_t lds = backward_lds_bytes<P>();
     static bool attr_set = false;       // raise the dynamic-LDS cap once per instantiation (fp32 images need > 64 KiB)
@@ -492,9 +501,10 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
             return fail(NAF_ERR_LAUNCH, "mlp_backward_kernel: cannot raise dynamic LDS limit");
         attr_set = true;
     }
+    if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
-                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation); }
+                       (typename P::feat_t::store_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
     { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + 255) / 256), dim3(256), 0, s, slabs, grid, grad_mlp); }
     return check_launch("mlp_grad_reduce_kernel");
@@ -504,13 +514,13 @@ template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                               const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
     using FT = typename P::feat_t;
-    constexpr uint32_t PPT = sizeof(Rec) <= 16 ? 2u : 1u;      // must match make_bin_plan
+    constexpr uint32_t PPT = sizeof(Rec) <= 8 ? 2u : 1u;      // must match make_bin_plan
     auto bin = scatter_bin_kernel<FT, C, SrcRays, Rec, PPT>;
     auto red = scatter_reduce_kernel<C, Rec>;
     const BinPlan &plan = w.plan;
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;
-    const uint32_t bin_lds = (3u * NB + 4u) * 4u + plan.tile_points * 8u * (uint32_t)sizeof(Rec);
+    const uint32_t bin_lds = NB * 4u + NB * plan.slot_cap * (uint32_t)sizeof(Rec);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)red, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(red_lds, 64u << 10)) != hipSuccess ||
@@ -521,7 +531,6 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     if (hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
     for (uint32_t l0 = 0; l0 < cfg->L; l0 += plan.levels_per_pass) {
         const uint32_t nl = std::min(plan.levels_per_pass, cfg->L - l0);
-        if (hipMemsetAsync(w.counts, 0, ((size_t)nl * NB * 4u) << plan.log2_sub, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
         static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
         static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
         const bool per_level = profile_levels();
@@ -530,8 +539,8 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
                              offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, plan); }
         if (int rc = check_launch("scatter_bin_kernel")) return rc;
         { ProfScope prof_(per_level ? level_name(red_names, l0) : "scatter_reduce_kernel", s);
-          hipLaunchKernelGGL(red, dim3(NB, nl), dim3(256), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                             grad_table, l0, plan); }
+          hipLaunchKernelGGL(red, dim3(NB, nl), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
+                             grad_table, w.gmax, l0, plan); }
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }
     return NAF_OK;
@@ -563,6 +572,9 @@ static SrcRays make_src(const float *rays, const float *t_rand, const naf_render
     SrcRays s;
     s.rays = rays; s.t_rand = t_rand; s.S = cfg->n_samples; s.perturb = cfg->perturb != 0; s.bound = cfg->bound;
     s.seed = cfg->seed; s.ray_base = cfg->ray_index_base;
+    s.div_magic = (uint32_t)((1ull << 32) / s.S);
+    s.lin_step = 1.0f / (float)(s.S - 1u);
+    s.rden = 1.0f / (2.0f * s.bound);
     return s;
 }
 
@@ -585,7 +597,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     const SrcRays src = make_src(rays, t_rand, cfg);
     if (!features_valid)
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, grad_mlp, n_rays, B, cfg, s)) return rc;
+    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, n_rays, B, cfg, s)) return rc;
     return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, s);
 }
 

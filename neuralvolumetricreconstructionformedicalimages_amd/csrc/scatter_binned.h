@@ -42,10 +42,12 @@ struct RecBF16 {                      // row + C bf16 values (packed two per dwo
     __device__ __forceinline__ void set(uint32_t row, const float (&v)[C]) {
         w[0] = row;
 #pragma unroll
-        for (uint32_t c = 0; c < C; c += 2) {
-            const uint32_t lo = f32_to_bf16(v[c]);
-            const uint32_t hi = c + 1 < C ? f32_to_bf16(v[c + 1]) : 0u;
-            w[1 + c / 2] = lo | (hi << 16);
+        for (uint32_t c = 0; c < C; c += 2) {              // plain casts: hipcc emits one v_cvt_pk_bf16_f32 per pair
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 pk;
+            pk[0] = (__bf16)v[c];
+            pk[1] = c + 1 < C ? (__bf16)v[c + 1] : (__bf16)0.0f;
+            w[1 + c / 2] = __builtin_bit_cast(uint32_t, pk);
         }
     }
     __device__ __forceinline__ float value(uint32_t c) const {
@@ -57,57 +59,58 @@ struct RecBF16 {                      // row + C bf16 values (packed two per dwo
 struct BinPlan {
     uint32_t tile_points;     // points per pass-1 workgroup = 256 * PPT
     uint32_t n_tiles;
-    uint32_t log2_nb;         // NB = buckets per level (multiple of 256)
-    uint32_t stream_cap;      // records per (level, bucket, sub) stream
-    uint32_t log2_sub;        // each bucket has 2^log2_sub sub-streams (tile % 2^log2_sub) so the cursors are not hot spots
+    uint32_t log2_nb;         // NB = buckets per level
+    uint32_t slot_cap;        // records per (level, bucket, tile) region = LDS slots per bucket in pass 1
     uint32_t levels_per_pass;
     uint32_t max_local_rows;  // ceil(max T_l / NB)
 };
 
-// exclusive prefix sum of one value per thread over a 256-thread workgroup; `scratch` holds >= 4 uint32
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *scratch, uint32_t &total) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off, 64);
-        if ((int)lane >= off) inc += t;
-    }
-    if (lane == 63u) scratch[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; ++w) base += scratch[w];
-    total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-    __syncthreads();
-    return base + inc - v;
+// Fixed-point scale of the reducer.  `gmax_bits` = bit pattern of max |feature gradient| of the step (written by the MLP
+// backward kernel); every contribution is w * g with 0 <= w <= 1, so |v| <= gmax < 2^(E+1) with E = exponent(gmax).
+// fixed = v * 2^(kFixHead - E - 1)  keeps |fixed| < 2^kFixHead and leaves 63 - kFixHead bits for the sum.
+constexpr int kFixHead = 37;
+__device__ __forceinline__ int fixed_shift(uint32_t gmax_bits) {
+    const int e = (int)((gmax_bits >> 23) & 0xffu);          // biased exponent of gmax; 0 -> all gradients are zero
+    return e == 0 ? 0 : kFixHead - (e - 127) - 1;
+}
+// fp32 -> 64-bit fixed point v * 2^shift (round to nearest, ties away) with integer ops only
+__device__ __forceinline__ long long to_fixed(float v, int shift) {
+    const uint32_t u = __float_as_uint(v);
+    const int e = (int)((u >> 23) & 0xffu);
+    if (e == 0) return 0;                                           // zero / denormal
+    long long m = (long long)((u & 0x7fffffu) | 0x800000u);         // 24-bit significand, value = m * 2^(e-150)
+    const int sh = e - 150 + shift;                                 // fixed = m * 2^sh
+    if (sh >= 0) m = sh < 39 ? (m << sh) : 0x3fffffffffffffffll;    // cannot happen for |v| <= gmax; saturate anyway
+    else m = sh > -25 ? ((m + (1ll << (-sh - 1))) >> (-sh)) : 0;
+    return (u >> 31) ? -m : m;
+}
+
+__device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
+    return (((size_t)ly << plan.log2_nb) + bucket) * plan.n_tiles + tile;
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: cnt[NB] | off[NB] | gbase[NB] | scratch[4] | staging[256 * PPT * 8] records.
-// PPT = points per thread: the rows and weights of a thread's PPT*8 contributions stay in registers between the
-// counting and the placement phase, so the index arithmetic runs once.
+// LDS: cnt[NB] | staging[NB][slot_cap] records.
 template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t PPT>
 __global__ void __launch_bounds__(256)
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
-                   float *__restrict__ grad_table, Rec *__restrict__ streams, uint32_t *__restrict__ cursors,
+                   float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t NB = 1u << plan.log2_nb, mask = NB - 1u;
+    const uint32_t NB = 1u << plan.log2_nb, mask = NB - 1u, CAP = plan.slot_cap;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *off = cnt + NB;
-    uint32_t *gbase = off + NB;
-    uint32_t *scratch = gbase + NB;
-    Rec *staging = reinterpret_cast<Rec *>(scratch + 4);
+    Rec *staging = reinterpret_cast<Rec *>(cnt + NB);
     const uint32_t ly = blockIdx.y, level = level_base + ly, tile = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < NB; i += 256u) cnt[i] = 0u;
     __syncthreads();
 
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
+    float *__restrict__ gg = grad_table + (size_t)m.offset * C;
     const uint32_t b0 = tile * (256u * PPT);
     // merge same-cell runs only where they exist: cells wider than the sample spacing (wave-uniform decision)
     const bool dedup = m.scale * src.sample_spacing() < 0.75f;
 
-    // A: rows + weights of this thread's contributions; count per bucket
+    // A: rows + values of this thread's contributions
     uint32_t row[PPT][8];
     float val[PPT][8][C];
     uint64_t cell[PPT];
@@ -159,111 +162,99 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
             }
         }
     }
+    // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
 #pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k)
+    for (uint32_t k = 0; k < PPT; ++k) {
+        uint32_t pos[8];
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c)
-            if (row[k][c] != 0xffffffffu) atomicAdd(&cnt[row[k][c] & mask], 1u);
-    __syncthreads();
-
-    // B: exclusive scan of the bucket counts (each thread owns NB/256 consecutive buckets) + global reservation
-    const uint32_t per = NB >> 8;
-    uint32_t mine = 0;
-    for (uint32_t k = 0; k < per; ++k) mine += cnt[threadIdx.x * per + k];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan_256(mine, scratch, total);
-    const uint32_t sub = tile & ((1u << plan.log2_sub) - 1u);
-    // stream id = ((ly * NB + bucket) << log2_sub) + sub
-    uint32_t *cur = cursors + (((size_t)ly << plan.log2_nb) << plan.log2_sub) + sub;
-    for (uint32_t k = 0; k < per; ++k) {
-        const uint32_t bkt = threadIdx.x * per + k, n = cnt[bkt];
-        off[bkt] = run;
-        run += n;
-        gbase[bkt] = n ? atomicAdd(&cur[(size_t)bkt << plan.log2_sub], n) : 0u;       // one returning atomic per non-empty bucket
+            pos[c] = row[k][c] != 0xffffffffu ? atomicAdd(&cnt[row[k][c] & mask], 1u) : 0xffffffffu;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            if (pos[c] == 0xffffffffu) continue;
+            if (pos[c] < CAP) {
+                Rec r;
+                r.set(row[k][c] >> plan.log2_nb, val[k][c]);
+                staging[(row[k][c] & mask) * CAP + pos[c]] = r;
+            } else {
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[k][c] * C + ch, val[k][c][ch]);
+                atomicAdd(overflow, 1u);
+            }
+        }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < NB; i += 256u) cnt[i] = off[i];     // running write positions
-    __syncthreads();
 
-    // C: place the records in bucket order in LDS
-    uint32_t pos[PPT][8];
-#pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k)
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            pos[k][c] = row[k][c] != 0xffffffffu ? atomicAdd(&cnt[row[k][c] & mask], 1u) : 0xffffffffu;
-#pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k)
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            if (pos[k][c] != 0xffffffffu) {
-                Rec r;
-                r.set(row[k][c], val[k][c]);
-                staging[pos[k][c]] = r;
-            }
-    __syncthreads();
-
-    // D: copy out; consecutive threads copy consecutive records of a bucket -> coalesced runs
-    float *__restrict__ gg = grad_table + (size_t)m.offset * C;
-    for (uint32_t j = threadIdx.x; j < total; j += 256u) {
-        Rec r = staging[j];
-        const uint32_t rw = r.w[0], bkt = rw & mask;
-        const uint32_t dst = gbase[bkt] + (j - off[bkt]);
-        if (dst < plan.stream_cap) {
-            r.w[0] = rw >> plan.log2_nb;
-            streams[((((size_t)ly << plan.log2_nb) + bkt) << plan.log2_sub | sub) * plan.stream_cap + dst] = r;
-        } else {                                               // stream full: still correct, just slower
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)rw * C + ch, r.value(ch));
-            atomicAdd(overflow, 1u);
-        }
+    // B: copy each bucket run to its region (one wave per bucket at a time: consecutive lanes, consecutive records)
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t bkt = wave; bkt < NB; bkt += 4u) {
+        const uint32_t n = min(cnt[bkt], CAP);
+        const size_t reg = region_index(plan, ly, bkt, tile);
+        Rec *__restrict__ dst = regions + reg * CAP;
+        for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+        if (lane == 0u) counts[reg] = n;
     }
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------------------
-// Accumulation is in DOUBLE: on gfx950 ds_add_f64 runs at ~2.5 lane-ops/clk/CU while ds_add_f32 manages 0.33
-// (tools/lds_atomic_bench.hip), and the sums come out more accurate than fp32 atomics as a bonus.
+// Accumulators are 64-bit FIXED POINT updated with ds_add_u64: integer LDS atomics run at 4.7 lane-ops/clk/CU on
+// gfx950 against 2.46 for ds_add_f64 and 0.33 for ds_add_f32 (tools/lds_atomic_bench.hip).  Integer addition is
+// associative, so the reduction is bit-reproducible from run to run.  The scale follows the largest feature gradient of
+// the step (fixed_shift): 37 significant bits below it, 26 bits of headroom above for the sum.
 template <uint32_t C, typename Rec>
-__global__ void __launch_bounds__(256)
-scatter_reduce_kernel(const Rec *__restrict__ streams, const uint32_t *__restrict__ cursors, const int32_t *__restrict__ offsets,
-                      float *__restrict__ grad_table, uint32_t level_base, BinPlan plan) {
+__global__ void __launch_bounds__(1024)
+scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                      float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *acc = reinterpret_cast<double *>(smem);
-    const uint32_t NB = 1u << plan.log2_nb;
+    const int shift = fixed_shift(*gmax_bits);
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
+    const uint32_t NB = 1u << plan.log2_nb, T_ = blockDim.x, CAP = plan.slot_cap;
     const uint32_t bucket = blockIdx.x, ly = blockIdx.y, level = level_base + ly;
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     const uint32_t rows_local = bucket < T ? (T - bucket + NB - 1u) >> plan.log2_nb : 0u;    // rows with row % NB == bucket
-    for (uint32_t i = threadIdx.x; i < rows_local * C; i += 256u) acc[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
-    constexpr uint32_t U = 8;                                   // records in flight per lane
-    for (uint32_t sub = 0; sub < (1u << plan.log2_sub); ++sub) {
-        const size_t stream = ((((size_t)ly << plan.log2_nb) + bucket) << plan.log2_sub) + sub;
-        const uint32_t n = min(cursors[stream], plan.stream_cap);
-        const Rec *__restrict__ recs = streams + stream * plan.stream_cap;
-        for (uint32_t i0 = 0; i0 < n; i0 += 256u * U) {
-            Rec r[U];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = T_ >> 6;
+    const size_t reg0 = region_index(plan, ly, bucket, 0);
+    auto add = [&](const Rec &r) {
 #pragma unroll
-            for (uint32_t u = 0; u < U; ++u) {                          // unconditional (clamped) loads: all U in flight at once
-                const uint32_t i = i0 + u * 256u + threadIdx.x;
-                r[u] = recs[i < n ? i : n - 1u];
+        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), shift));   // ds_add_u64
+    };
+    // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths
+    for (uint32_t t0 = wave * 64u; t0 < plan.n_tiles; t0 += n_waves * 64u) {
+        const uint32_t mine = t0 + lane < plan.n_tiles ? counts[reg0 + t0 + lane] : 0u;
+        const uint32_t n_here = min(64u, plan.n_tiles - t0);
+        for (uint32_t j = 0; j < n_here; j += 4u) {
+            uint32_t n[4];
+            Rec ra[4], rb[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {                         // four regions (eight loads) in flight per wave
+                const uint32_t tj = min(j + u, n_here - 1u);
+                n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
+                const Rec *__restrict__ src_r = regions + (reg0 + t0 + tj) * CAP;
+                // loads are unconditional (so the compiler keeps them all in flight); lanes past the run length read
+                // slot 0, i.e. a line that is fetched anyway -> no extra traffic for the unused part of a region
+                ra[u] = src_r[lane < n[u] ? lane : 0u];
+                rb[u] = src_r[lane + 64u < n[u] ? lane + 64u : 0u];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < U; ++u) {
-                const uint32_t i = i0 + u * 256u + threadIdx.x;
-                if (i < n) {
-#pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r[u].w[0] * C + ch], (double)r[u].value(ch));     // ds_add_f64
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (lane < n[u]) add(ra[u]);
+                if (lane + 64u < n[u]) add(rb[u]);
+                if (n[u] > 128u) {                                      // only for slot_cap > 128 (not used by the planner)
+                    const Rec *__restrict__ src_r = regions + (reg0 + t0 + min(j + u, n_here - 1u)) * CAP;
+                    for (uint32_t slot = 128u + lane; slot < n[u]; slot += 64u) add(src_r[slot]);
                 }
             }
         }
     }
     __syncthreads();
     float *__restrict__ gg = grad_table + (size_t)off * C;
-    for (uint32_t i = threadIdx.x; i < rows_local * C; i += 256u) {
+    for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
         const uint32_t local = i / C, ch = i - local * C;
         const size_t dst = ((size_t)local << plan.log2_nb) + bucket;
-        gg[dst * C + ch] += (float)acc[i];                        // sole owner of these rows in this launch
+        gg[dst * C + ch] += (float)ldexp((double)(long long)acc[i], -shift);          // sole owner of these rows
     }
 }
 
