@@ -1,0 +1,81 @@
+"""Data-parallel training step on the real engine: two processes (gloo transport, both on the one GPU of the test
+box) shard a ray batch, all-reduce the gradients and must end with the parameters of a single process that trained on
+the whole batch.  On a multi-GPU node the same code runs with backend "nccl" (RCCL), one process per GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(seed=0):
+    from neuralvolumetricreconstructionformedicalimages_amd.encoder import HashEncoder
+    from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
+    torch.manual_seed(seed)
+    enc = HashEncoder(3, 16, 2, 16, 14)
+    enc.embeddings.data.uniform_(-0.1, 0.1)
+    net = DensityNetwork(enc, bound=0.3, num_layers=4, hidden_dim=32, skips=[2], out_dim=1, last_activation="sigmoid")
+    return net.cuda()
+
+
+def _batch(n=256, S=64):
+    g = torch.Generator().manual_seed(11)
+    ang = torch.rand(n, generator=g) * 6.283
+    o = torch.stack([torch.cos(ang), torch.sin(ang), torch.zeros(n)], -1)
+    d = (torch.rand(n, 3, generator=g) - 0.5) * 0.4 - o
+    rays = torch.cat([o, d, torch.full((n, 1), 0.6), torch.full((n, 1), 1.4)], -1)
+    return rays, torch.rand(n, S, generator=g), torch.rand(n, generator=g) * 0.3, torch.rand(n, generator=g) > 0.2
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as td
+    from neuralvolumetricreconstructionformedicalimages_amd import dist
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    td.init_process_group("gloo")
+    group = td.group.WORLD
+    net = _make(seed=0 if rank == 0 else 99)                      # rank 1 starts different until the broadcast
+    S = 64
+    engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=group)
+    dist.broadcast_parameters([engine.emb, engine.mlp], group)
+    rays, t_rand, target, mask = _batch(S=S)
+    b, e = dist.shard_range(rays.shape[0], rank, world)
+    for _ in range(3):
+        w = dist.global_mean_weights(mask[b:e].cuda(), group)
+        engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, t_rand=t_rand[b:e].cuda().contiguous())
+    torch.cuda.synchronize()
+    out.put((rank, engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item())))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_rank_training_equals_single_process():
+    from neuralvolumetricreconstructionformedicalimages_amd import dist
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    net = _make(seed=0)
+    S = 64
+    engine = NAFEngine(net, S, perturb=True, lr=1e-2)
+    rays, t_rand, target, mask = _batch(S=S)
+    for _ in range(3):
+        w = dist.global_mean_weights(mask.cuda(), None)
+        engine.train_step(rays.cuda(), target.cuda(), w, t_rand=t_rand.cuda())
+    emb, mlp, loss = engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item())
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])    # replicas agree
+    # Adam steps of +-lr amplify rounding of near-zero gradients, hence the absolute tolerance of a fraction of lr
+    np.testing.assert_allclose(results[0][2], mlp, rtol=0, atol=2e-4)
+    assert np.mean(np.abs(results[0][1] - emb) > 2e-3) < 1e-3
+    np.testing.assert_allclose(results[0][3], loss, rtol=1e-3)

@@ -256,3 +256,32 @@ def test_binned_scatter_equals_atomic_scatter(prec):
     tol = 1e-5 if prec == "f32" else 3e-3          # bf16 records round each contribution once more (2^-9 relative)
     assert float((a - b).norm() / a.norm()) < tol
     assert float((a - b).abs().max() / a.abs().max()) < 10 * tol
+
+
+def test_foot_config_t22_fp16_table_and_long_rays():
+    """foot_50-like shapes (BASELINE.json configs[4]): T=2^22 (wrapped-dense fine levels, 512 scatter buckets), fp16
+    table, S=320 -- forward vs the oracle, binned vs atomic gradient."""
+    _abi, encoder, fused, network = _mods()
+    from oracle import render_ref as R
+    net, ref = _naf_pair(seed=9, log2T=22, scale=0.05)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.half()
+    ref.encoder.embeddings.data.copy_(net.encoder.embeddings.data.float().cpu())
+    S, n = 320, 24
+    rays = _rays(n, seed=19)
+    t_rand = torch.rand(n, S)
+    with torch.no_grad():
+        want = R.render(rays, ref, None, S, 0, True, 1 << 20, 0.0, t_rand=t_rand)["acc"].numpy()
+    target = torch.rand(n, device="cuda") * 0.3
+    grads = {}
+    try:
+        for mode in (1, 2):
+            _abi.check(_abi.lib().naf_set_scatter_mode(mode))
+            net.zero_grad()
+            acc = fused.fused_render(rays.cuda(), net, S, True, t_rand=t_rand.cuda())
+            (1e4 * (acc - target) ** 2).mean().backward()             # scaled: the gradient comes back in fp16 (table dtype)
+            grads[mode] = net.encoder.embeddings.grad.float().clone()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    assert _rel_l2(acc.detach().cpu().numpy(), want) < 1e-2          # bf16 MFMA operands
+    a, b = grads[1].double(), grads[2].double()
+    assert float((a - b).norm() / a.norm()) < 5e-3                   # bf16 records + both rounded to fp16 at the end
