@@ -149,12 +149,39 @@ class HashEncoder(nn.Module):
         return outputs.view(prefix_shape + [self.output_dim])
 
 
+class FreqEncoder(nn.Module):
+    """NeRF-style sin/cos positional encoding: mirror of reference src/encoder/freqencoder.py:5-42.
+
+    No reference config selects it (config/*.yaml:14 all use "hashgrid"), so it is plain tensor ops on the device the
+    input lives on rather than a hand-written kernel; it exists so that `get_encoder("frequency")` keeps working."""
+
+    def __init__(self, input_dim, max_freq_log2, N_freqs, log_sampling=True, include_input=True,
+                 periodic_fns=(torch.sin, torch.cos)):
+        super().__init__()
+        self.input_dim = input_dim
+        self.include_input = include_input
+        self.periodic_fns = periodic_fns
+        self.output_dim = (input_dim if include_input else 0) + input_dim * N_freqs * len(periodic_fns)
+        if log_sampling:
+            bands = 2.0 ** torch.linspace(0.0, max_freq_log2, N_freqs)
+        else:
+            bands = torch.linspace(2.0 ** 0.0, 2.0 ** max_freq_log2, N_freqs)
+        self.freq_bands = bands.numpy().tolist()
+
+    def forward(self, input, bound):
+        out = [input] if self.include_input else []
+        for freq in self.freq_bands:
+            out += [fn(input * freq) for fn in self.periodic_fns]
+        return torch.cat(out, dim=-1)
+
+
 def get_encoder(encoding, input_dim=3, multires=6, degree=4, num_levels=16, level_dim=2, base_resolution=16,
                 log2_hashmap_size=19, **kwargs):
     if encoding == "None":
         return lambda x, **kwargs: x, input_dim
+    if encoding == "frequency":
+        return FreqEncoder(input_dim=input_dim, max_freq_log2=multires - 1, N_freqs=multires, log_sampling=True)
     if encoding == "hashgrid":
         return HashEncoder(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim,
                            base_resolution=base_resolution, log2_hashmap_size=log2_hashmap_size)
-    # "frequency" (src/encoder/freqencoder.py) is outside the hot-path scope: no config uses it
     raise NotImplementedError()

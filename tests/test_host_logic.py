@@ -20,6 +20,11 @@ def test_level_offsets_match_oracle():
         encoder.HashEncoder(3, 16, 3, 16, 19)
     with pytest.raises(NotImplementedError):
         encoder.get_encoder("spherical")
+    fe = encoder.get_encoder("frequency", input_dim=3, multires=6)          # freqencoder.py:5-42
+    x = torch.rand(5, 3)
+    y = fe(x, 0.3)
+    assert fe.output_dim == 3 + 3 * 6 * 2 and y.shape == (5, 39)
+    assert torch.equal(y[:, :3], x) and torch.allclose(y[:, 3:6], torch.sin(x)) and torch.allclose(y[:, 36:39], torch.cos(x * 32.0))
 
 
 def _geo(g, name):
