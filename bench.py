@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16", help="table storage / MLP operand type")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
+    ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +133,7 @@ def main():
                          last_activation="sigmoid").to(device)
     tdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
     engine = NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"], table_dtype=tdt, seed=args.seed,
-                       process_group=pg)
+                       process_group=pg, n_streams=args.streams, chunk_rays=args.chunk_rays)
 
     # ---- per-step inputs, resident in HBM before the clock starts ------------------------------------------------
     n = args.rays

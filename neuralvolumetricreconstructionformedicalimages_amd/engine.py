@@ -21,7 +21,7 @@ from . import fused
 
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
-                 mlp_precision=None, seed=0, process_group=None):
+                 mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -59,6 +59,15 @@ class NAFEngine:
         self.mlp_precision = mlp_precision
         if mlp_precision is None:
             self.mlp_precision = _abi.F32 if table_dtype == torch.float32 else _abi.BF16
+        # Optional multi-stream execution: the batch is cut into chunks that run their whole forward/backward pipeline on
+        # alternating HIP streams, so the gather-bound, VALU-bound and store-bound kernels of different chunks overlap.
+        # Each extra stream owns a gradient buffer, a workspace and a loss cell; they are summed before Adam.
+        self.n_streams = max(1, int(n_streams))
+        self.chunk_rays = int(chunk_rays)
+        self._lanes = []
+        for _ in range(self.n_streams - 1):
+            self._lanes.append({"stream": torch.cuda.Stream(device=dev), "emb_g": torch.zeros_like(self.emb),
+                                "mlp_g": torch.zeros_like(self.mlp), "loss": torch.zeros(1, device=dev), "ws": None})
 
     # -------------------------------------------------------------------------------------------------------
     def _cfg(self, ray_base=0):
@@ -74,18 +83,59 @@ class NAFEngine:
     def table(self):
         return self.emb if self.emb_lp is None else self.emb_lp
 
+    def _launch(self, rays, target, weight, t_rand, ray_base, acc, emb_g, mlp_g, loss, ws):
+        n = rays.shape[0]
+        cfg = self._cfg(ray_base)
+        _abi.check(_abi.lib().naf_render_train(
+            _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
+            _abi.ptr(self.mlp), _abi.ptr(acc), _abi.ptr(emb_g), _abi.ptr(mlp_g), _abi.ptr(loss), n,
+            ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_train")
+
     def backward(self, rays, target, weight, t_rand=None, ray_base=0):
         """Forward + weighted squared error + backward: fills the gradient buffers, returns acc [n]."""
         n = rays.shape[0]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
-        cfg = self._cfg(ray_base)
-        ws = fused.workspace(cfg, n * self.n_samples, self.device)
         self.loss.zero_()
-        _abi.check(_abi.lib().naf_render_train(
-            _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
-            _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
-            ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_train")
+        if self.n_streams == 1 or n <= self.chunk_rays:
+            cfg = self._cfg(ray_base)
+            ws = fused.workspace(cfg, n * self.n_samples, self.device)
+            self._launch(rays, target, weight, t_rand, ray_base, self.acc, self.emb_g, self.mlp_g, self.loss, ws)
+            fused._bump(self.device)
+            return self.acc[:n]
+        return self._backward_multistream(rays, target, weight, t_rand, ray_base)
+
+    def _backward_multistream(self, rays, target, weight, t_rand, ray_base):
+        n, c = rays.shape[0], self.chunk_rays
+        main = torch.cuda.current_stream()
+        cfg = self._cfg(ray_base)
+        need = int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), c * self.n_samples))
+        lanes = [{"stream": main, "emb_g": self.emb_g, "mlp_g": self.mlp_g, "loss": self.loss,
+                  "ws": fused.workspace(cfg, c * self.n_samples, self.device)}] + self._lanes
+        start = torch.cuda.Event()
+        start.record(main)
+        for lane in lanes[1:]:
+            if lane["ws"] is None or lane["ws"].numel() < need:
+                lane["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            lane["stream"].wait_event(start)                # inputs and parameters are ready
+            with torch.cuda.stream(lane["stream"]):
+                lane["loss"].zero_()
+        for k, b in enumerate(range(0, n, c)):
+            e = min(n, b + c)
+            lane = lanes[k % len(lanes)]
+            with torch.cuda.stream(lane["stream"]):
+                tr = None if t_rand is None else t_rand[b:e]
+                self._launch(rays[b:e], target[b:e], weight[b:e], tr, ray_base + b, self.acc[b:e], lane["emb_g"], lane["mlp_g"],
+                             lane["loss"], lane["ws"])
+        for lane in lanes[1:]:                              # fold the side streams' gradients into the main buffers
+            done = torch.cuda.Event()
+            done.record(lane["stream"])
+            main.wait_event(done)
+            self.emb_g.add_(lane["emb_g"])
+            self.mlp_g.add_(lane["mlp_g"])
+            self.loss.add_(lane["loss"])
+            lane["emb_g"].zero_()
+            lane["mlp_g"].zero_()
         fused._bump(self.device)
         return self.acc[:n]
 
