@@ -185,13 +185,20 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     }
     __syncthreads();
 
-    // B: copy each bucket run to its region (one wave per bucket at a time: consecutive lanes, consecutive records)
+    // B: copy each bucket run to its region (one wave per bucket at a time: consecutive lanes, consecutive records);
+    //    8-byte records travel two per lane as 16-byte LDS reads / global stores (slot_cap is even)
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t bkt = wave; bkt < NB; bkt += 4u) {
         const uint32_t n = min(cnt[bkt], CAP);
         const size_t reg = region_index(plan, ly, bkt, tile);
         Rec *__restrict__ dst = regions + reg * CAP;
-        for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+        if constexpr (sizeof(Rec) == 8) {
+            const uint4 *src16 = reinterpret_cast<const uint4 *>(staging + bkt * CAP);
+            uint4 *dst16 = reinterpret_cast<uint4 *>(dst);
+            for (uint32_t pair = lane; 2u * pair < n; pair += 64u) dst16[pair] = src16[pair];   // may copy one stale slot: harmless
+        } else {
+            for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+        }
         if (lane == 0u) counts[reg] = n;
     }
 }
@@ -229,12 +236,10 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
             uint32_t n[4];
             Rec ra[4], rb[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {                         // four regions (eight loads) in flight per wave
+            for (uint32_t u = 0; u < 4u; ++u) {                     // four regions (eight loads) in flight per wave
                 const uint32_t tj = min(j + u, n_here - 1u);
                 n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
                 const Rec *__restrict__ src_r = regions + (reg0 + t0 + tj) * CAP;
-                // loads are unconditional (so the compiler keeps them all in flight); lanes past the run length read
-                // slot 0, i.e. a line that is fetched anyway -> no extra traffic for the unused part of a region
                 ra[u] = src_r[lane < n[u] ? lane : 0u];
                 rb[u] = src_r[lane + 64u < n[u] ? lane + 64u : 0u];
             }
