@@ -60,6 +60,20 @@ __device__ __forceinline__ float wave_sum32(float v) {   // sum over the 32 lane
     return v;
 }
 
+// Per-wave depth buffer: the S depths of the current ray are evaluated once (lanes stride the samples) and kept in LDS,
+// so the sample distances of all tiles of the ray are two LDS reads instead of two jitter/depth evaluations per point.
+constexpr uint32_t kMaxSamplesLds = 1024;
+__device__ __forceinline__ void fill_depths(const SrcRays &src, uint32_t r, float near, float far, float *zbuf, uint32_t lane) {
+    for (uint32_t s = lane; s < src.S; s += 64u) zbuf[s] = src.depth(r, s, near, far);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float buffered_dist(const float *zbuf, uint32_t s, uint32_t S, float dnorm) {
+    if (s + 1u >= S) return 1e-10f * dnorm;
+    return (zbuf[s + 1u] - zbuf[s]) * dnorm;
+}
+
 // dist of sample s on ray r (render.py:192-194): (z[s+1]-z[s]) * |d|, last sample 1e-10 * |d|
 __device__ __forceinline__ float sample_dist(const SrcRays &src, uint32_t r, uint32_t s, float near, float far, float dnorm) {
     if (s + 1u >= src.S) return 1e-10f * dnorm;
@@ -81,10 +95,13 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
 
     if constexpr (kRays) {
         const uint32_t S = src.S, tiles = (S + 31u) / 32u;
+        const bool use_zbuf = S <= kMaxSamplesLds;
+        float *zbuf = reinterpret_cast<float *>(smem + ((MlpShared<P>::kBytes + 15u) & ~15u)) + (threadIdx.x >> 6) * kMaxSamplesLds;
         for (uint32_t r = wave; r < n_items; r += n_waves) {
             const float *ray = src.rays + (size_t)r * 8;
             const float near = ray[6], far = ray[7];
             const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+            if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
             float part = 0.0f;
             for (uint32_t k = 0; k < tiles; ++k) {
                 const uint32_t s = 32u * k + n;
@@ -93,7 +110,8 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
                 load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
                 const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
                 const float sigma = last_act(act, z4);
-                if (valid && h == 0) part += sigma * sample_dist(src, r, s, near, far, dnorm);
+                if (valid && h == 0)
+                    part += sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
             }
             part = wave_sum32(part);
             if (lane == 0) out[r] = part;
@@ -138,6 +156,9 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
     TR *imgA = reinterpret_cast<TR *>(smem + kShAligned) + (size_t)wib * 3u * kImg;   // gradient tile  G
     TR *imgB = imgA + kImg;                                                        // input tile     X0
     TR *imgC = imgB + kImg;                                                        // hidden tile    H2 / H1
+    constexpr uint32_t kImgBytes = ((4u * 3u * kImg * (uint32_t)sizeof(TR)) + 15u) & ~15u;
+    float *zbuf = reinterpret_cast<float *>(smem + kShAligned + kImgBytes) + wib * kMaxSamplesLds;
+    const bool use_zbuf = src.S <= kMaxSamplesLds;
 
     // weight-gradient accumulators: lane (c,h), register t  <->  dW[out = slot_row(t,h)][in = c]
     f32x16 dW0 = {0}, dW1 = {0}, dW2a = {0}, dW2b = {0};
@@ -155,6 +176,7 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
         const float near = ray[6], far = ray[7];
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
         const float dacc = grad_acc[r];
+        if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
 
         for (uint32_t k = 0; k < tiles; ++k) {
             const uint32_t s = 32u * k + n;
@@ -165,7 +187,8 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
             const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
             const float sigma = last_act(act, z4);
-            const float gsig = valid ? dacc * sample_dist(src, r, s, near, far, dnorm) : 0.0f;
+            const float gsig = !valid ? 0.0f
+                             : dacc * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
             const float g4 = gsig * last_act_grad(act, z4, sigma);
 
             // output layer: dw3 += g4 * h3, db3 += g4 ; G3 = (w3 g4) * lrelu'(z3)
@@ -323,12 +346,12 @@ mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float 
 constexpr uint32_t kBackwardBlocks = 512;   // 2 workgroups of 4 waves per CU; also the number of dW slabs
 
 template <typename P>
-static uint32_t forward_lds_bytes() { return MlpShared<P>::kBytes; }
+static uint32_t forward_lds_bytes() { return ((MlpShared<P>::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u; }
 template <typename P>
 static uint32_t backward_lds_bytes() {
     const uint32_t sh = (MlpShared<P>::kBytes + 15u) & ~15u;
-    const uint32_t imgs = 4u * 3u * 32u * P::kTrPitch * (uint32_t)sizeof(typename P::tr_t);
-    return sh + std::max<uint32_t>(imgs, (kMlpParams + 1u) * 4u);
+    const uint32_t imgs = ((4u * 3u * 32u * P::kTrPitch * (uint32_t)sizeof(typename P::tr_t)) + 15u) & ~15u;
+    return sh + std::max<uint32_t>(imgs + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
 }
 
 struct Workspace {
