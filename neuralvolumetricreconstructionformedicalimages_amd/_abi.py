@@ -66,9 +66,15 @@ def lib():
     if _lib is None:
         path = library_path()
         if not os.path.exists(path):
-            raise RuntimeError(
-                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the NAF hot path.")
+            # a fresh checkout has sources only (*.so is git-ignored): compile them now if the ROCm toolchain is here;
+            # there is no other way to run -- no CPU fallback exists for the NAF hot path
+            try:
+                _build.build_library()
+            except Exception as e:
+                raise RuntimeError(
+                    f"{path} not found and could not be built ({e}).  Build it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                    "There is no CPU fallback for the NAF hot path.") from e
         handle = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
