@@ -367,7 +367,8 @@ struct Workspace {
 };
 
 constexpr uint64_t kBinMinPoints = 1u << 17;             // below this the plain atomic kernel is launch-bound anyway
-constexpr size_t kBinBudgetBytes = (size_t)6 << 30;      // stream buffer per pass; more levels per pass = fewer launches
+constexpr size_t kBinBudgetBytes = (size_t)24 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
+                                                         // step fit, so the reducer gets 1024 workgroups to balance over 256 CUs
 
 static size_t record_bytes(const naf_render_cfg *cfg) {
     return cfg->mlp_precision == NAF_F32 ? 4u * (1u + cfg->C) : 4u * (1u + (cfg->C + 1u) / 2u);

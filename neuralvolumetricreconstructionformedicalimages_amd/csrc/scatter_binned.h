@@ -228,15 +228,21 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), shift));   // ds_add_u64
     };
-    // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths
-    for (uint32_t t0 = wave * 64u; t0 < plan.n_tiles; t0 += n_waves * 64u) {
-        const uint32_t mine = t0 + lane < plan.n_tiles ? counts[reg0 + t0 + lane] : 0u;
-        const uint32_t n_here = min(64u, plan.n_tiles - t0);
-        for (uint32_t j = 0; j < n_here; j += 4u) {
-            uint32_t n[4];
-            Rec ra[4], rb[4];
+    // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
+    // kGroup at a time with straight-line code: 2*kGroup unconditional loads per lane are in flight before the first
+    // LDS atomic (lanes past a run length read slot 0, a line that is fetched anyway -> no extra traffic).
+    constexpr uint32_t kGroup = 8;
+    // every wave streams ONE contiguous range of tiles (regions of consecutive tiles are adjacent in memory)
+    const uint32_t per_wave = (((plan.n_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
+    const uint32_t t_begin = wave * per_wave, t_end = min(plan.n_tiles, t_begin + per_wave);
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
+        const uint32_t mine = t0 + lane < t_end ? counts[reg0 + t0 + lane] : 0u;
+        const uint32_t n_here = min(64u, t_end - t0);
+        for (uint32_t j = 0; j < n_here; j += kGroup) {
+            uint32_t n[kGroup];
+            Rec ra[kGroup], rb[kGroup];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {                     // four regions (eight loads) in flight per wave
+            for (uint32_t u = 0; u < kGroup; ++u) {
                 const uint32_t tj = min(j + u, n_here - 1u);
                 n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
                 const Rec *__restrict__ src_r = regions + (reg0 + t0 + tj) * CAP;
@@ -244,7 +250,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                 rb[u] = src_r[lane + 64u < n[u] ? lane + 64u : 0u];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
+            for (uint32_t u = 0; u < kGroup; ++u) {
                 if (lane < n[u]) add(ra[u]);
                 if (lane + 64u < n[u]) add(rb[u]);
                 if (n[u] > 128u) {                                      // only for slot_cap > 128 (not used by the planner)
