@@ -389,7 +389,8 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
     const uint32_t slot_mean = std::max<uint32_t>(1u, (tile * 8u) >> log2_nb);
-    plan->slot_cap = (slot_mean + slot_mean / 2u + 8u + 1u) & ~1u;               // Poisson tail beyond this is < 1e-4; even
+    plan->slot_cap = std::min(128u, (slot_mean + slot_mean / 2u + 8u + 1u) & ~1u);  // Poisson tail beyond this is < 1e-4; even;
+                                                                                // <= 128: the reducer reads a region with two loads per lane
     plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
     const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));

@@ -73,16 +73,11 @@ __device__ __forceinline__ int fixed_shift(uint32_t gmax_bits) {
     const int e = (int)((gmax_bits >> 23) & 0xffu);          // biased exponent of gmax; 0 -> all gradients are zero
     return e == 0 ? 0 : kFixHead - (e - 127) - 1;
 }
-// fp32 -> 64-bit fixed point v * 2^shift (round to nearest, ties away) with integer ops only
-__device__ __forceinline__ long long to_fixed(float v, int shift) {
-    const uint32_t u = __float_as_uint(v);
-    const int e = (int)((u >> 23) & 0xffu);
-    if (e == 0) return 0;                                           // zero / denormal
-    long long m = (long long)((u & 0x7fffffu) | 0x800000u);         // 24-bit significand, value = m * 2^(e-150)
-    const int sh = e - 150 + shift;                                 // fixed = m * 2^sh
-    if (sh >= 0) m = sh < 39 ? (m << sh) : 0x3fffffffffffffffll;    // cannot happen for |v| <= gmax; saturate anyway
-    else m = sh > -25 ? ((m + (1ll << (-sh - 1))) >> (-sh)) : 0;
-    return (u >> 31) ? -m : m;
+// fp32 -> 64-bit fixed point round(v * 2^shift), branch-free: the product is exact in double, and adding 1.5 * 2^52
+// leaves the (two's complement) integer in the low mantissa bits for |v * 2^shift| < 2^51 (here < 2^38).
+__device__ __forceinline__ long long to_fixed(float v, double scale) {
+    const double d = (double)v * scale + 6755399441055744.0;
+    return __double_as_longlong(d) - 0x4338000000000000ll;
 }
 
 __device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
@@ -214,6 +209,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                       float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int shift = fixed_shift(*gmax_bits);
+    const double scale = ldexp(1.0, shift);
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t NB = 1u << plan.log2_nb, T_ = blockDim.x, CAP = plan.slot_cap;
     const uint32_t bucket = blockIdx.x, ly = blockIdx.y, level = level_base + ly;
@@ -226,7 +222,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const size_t reg0 = region_index(plan, ly, bucket, 0);
     auto add = [&](const Rec &r) {
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), shift));   // ds_add_u64
+        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
     };
     // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
     // kGroup at a time with straight-line code: 2*kGroup unconditional loads per lane are in flight before the first
@@ -251,12 +247,8 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
             }
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) {
-                if (lane < n[u]) add(ra[u]);
-                if (lane + 64u < n[u]) add(rb[u]);
-                if (n[u] > 128u) {                                      // only for slot_cap > 128 (not used by the planner)
-                    const Rec *__restrict__ src_r = regions + (reg0 + t0 + min(j + u, n_here - 1u)) * CAP;
-                    for (uint32_t slot = 128u + lane; slot < n[u]; slot += 64u) add(src_r[slot]);
-                }
+                if (lane < n[u]) add(ra[u]);                            // slot_cap <= 128 (planner invariant): two loads
+                if (lane + 64u < n[u]) add(rb[u]);                      // per lane cover a whole region
             }
         }
     }
