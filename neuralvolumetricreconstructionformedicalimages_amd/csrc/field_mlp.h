@@ -195,7 +195,7 @@ __device__ __forceinline__ f32x16 splat_slots(const float (&x)[16]) {
 }
 __device__ __forceinline__ void leaky_inplace(f32x16 &z, float (&out)[16]) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) out[t] = z[t] > 0.0f ? z[t] : kLeaky * z[t];
+    for (int t = 0; t < 16; ++t) out[t] = fmaxf(z[t], kLeaky * z[t]);      // slope < 1: max(z, 0.01 z) == LeakyReLU(z), 2 ops
 }
 
 // final activation and its derivative expressed through the OUTPUT y (network.py:23-32)
