@@ -180,21 +180,38 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     }
     __syncthreads();
 
-    // B: copy each bucket run to its region (one wave per bucket at a time: consecutive lanes, consecutive records);
-    //    8-byte records travel two per lane as 16-byte LDS reads / global stores (slot_cap is even)
+    // B: copy each bucket run to its region.  A wave owns buckets wave, wave+4, ...; it takes them kCopy at a time with
+    //    straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of several
+    //    buckets overlap.  8-byte records travel two per lane as 16-byte LDS reads / global stores (slot_cap even, <= 128).
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t bkt = wave; bkt < NB; bkt += 4u) {
-        const uint32_t n = min(cnt[bkt], CAP);
-        const size_t reg = region_index(plan, ly, bkt, tile);
-        Rec *__restrict__ dst = regions + reg * CAP;
-        if constexpr (sizeof(Rec) == 8) {
-            const uint4 *src16 = reinterpret_cast<const uint4 *>(staging + bkt * CAP);
-            uint4 *dst16 = reinterpret_cast<uint4 *>(dst);
-            for (uint32_t pair = lane; 2u * pair < n; pair += 64u) dst16[pair] = src16[pair];   // may copy one stale slot: harmless
-        } else {
-            for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+    if constexpr (sizeof(Rec) == 8) {
+        constexpr uint32_t kCopy = 4;
+        const uint32_t pairs = CAP >> 1;
+        const uint32_t my_pair = min(lane, pairs - 1u);
+        for (uint32_t base = wave; base < NB; base += 4u * kCopy) {
+            uint32_t nrun[kCopy];
+            uint4 v[kCopy];
+#pragma unroll
+            for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + 4u * k, NB - 1u)], CAP);
+#pragma unroll
+            for (uint32_t k = 0; k < kCopy; ++k)
+                v[k] = reinterpret_cast<const uint4 *>(staging + min(base + 4u * k, NB - 1u) * CAP)[my_pair];
+#pragma unroll
+            for (uint32_t k = 0; k < kCopy; ++k) {
+                const uint32_t bkt = base + 4u * k;
+                const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
+                if (bkt < NB && 2u * lane < nrun[k]) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // may carry one stale slot: harmless
+                if (bkt < NB && lane == 0u) counts[reg] = nrun[k];
+            }
         }
-        if (lane == 0u) counts[reg] = n;
+    } else {
+        for (uint32_t bkt = wave; bkt < NB; bkt += 4u) {
+            const uint32_t n = min(cnt[bkt], CAP);
+            const size_t reg = region_index(plan, ly, bkt, tile);
+            Rec *__restrict__ dst = regions + reg * CAP;
+            for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+            if (lane == 0u) counts[reg] = n;
+        }
     }
 }
 
