@@ -382,15 +382,17 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
-    // pass-1 tile: 256 threads x PPT points; its records wait in LDS slots [bucket][slot_cap]
-    const uint32_t ppt = record_bytes(cfg) <= 8 ? 2u : 1u;
-    const uint32_t tile = 256u * ppt;
+    // pass-1 tile: one point per thread, 512 threads for 8-byte records; its records wait in LDS slots [bucket][slot_cap]
+    const uint32_t tile = record_bytes(cfg) <= 8 ? 512u : 256u;
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
     const uint32_t slot_mean = std::max<uint32_t>(1u, (tile * 8u) >> log2_nb);
-    plan->slot_cap = std::min(128u, (slot_mean + slot_mean / 2u + 8u + 1u) & ~1u);  // Poisson tail beyond this is < 1e-4; even;
-                                                                                // <= 128: the reducer reads a region with two loads per lane
+    // 1.5 x mean + 8: the Poisson tail beyond it is < 1e-4 (overflow is still correct, just slower); even; <= 128 because the
+    // reducer reads a region with two loads per lane.  For 512-point tiles this is 104 slots = 832 B = 13 x 64 B per region:
+    // an odd multiple of 64 B spreads consecutive regions over the memory channels (measured bin time per step with 96 /
+    // 104 / 112 / 128 slots: 4.84 / 4.69 / 5.52 / 5.47 ms).
+    plan->slot_cap = std::min(128u, (slot_mean + slot_mean / 2u + 8u + 1u) & ~1u);
     plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
     const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
@@ -539,8 +541,8 @@ template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                               const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
     using FT = typename P::feat_t;
-    constexpr uint32_t PPT = sizeof(Rec) <= 8 ? 2u : 1u;      // must match make_bin_plan
-    auto bin = scatter_bin_kernel<FT, C, SrcRays, Rec, PPT>;
+    constexpr uint32_t PPT = 1u, NT = sizeof(Rec) <= 8 ? 512u : 256u;      // tile = NT * PPT, must match make_bin_plan
+    auto bin = scatter_bin_kernel<FT, C, SrcRays, Rec, PPT, NT>;
     auto red = scatter_reduce_kernel<C, Rec>;
     const BinPlan &plan = w.plan;
     const uint32_t NB = 1u << plan.log2_nb;
@@ -560,11 +562,13 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
         static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
         const bool per_level = profile_levels();
         { ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
-          hipLaunchKernelGGL(bin, dim3(plan.n_tiles, nl), dim3(256), bin_lds, s, src, (const typename FT::store_t *)dfeat,
+          hipLaunchKernelGGL(bin, dim3(plan.n_tiles, nl), dim3(NT), bin_lds, s, src, (const typename FT::store_t *)dfeat,
                              offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, plan); }
         if (int rc = check_launch("scatter_bin_kernel")) return rc;
         { ProfScope prof_(per_level ? level_name(red_names, l0) : "scatter_reduce_kernel", s);
-          hipLaunchKernelGGL(red, dim3(NB, nl), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
+          // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles
+          const uint32_t n_split = std::max(1u, std::min(16u, 1024u / (NB * nl)));
+          hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
                              grad_table, w.gmax, l0, plan); }
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }

@@ -57,7 +57,7 @@ struct RecBF16 {                      // row + C bf16 values (packed two per dwo
 };
 
 struct BinPlan {
-    uint32_t tile_points;     // points per pass-1 workgroup = 256 * PPT
+    uint32_t tile_points;     // points per pass-1 workgroup = NT * PPT
     uint32_t n_tiles;
     uint32_t log2_nb;         // NB = buckets per level
     uint32_t slot_cap;        // records per (level, bucket, tile) region = LDS slots per bucket in pass 1
@@ -85,9 +85,11 @@ __device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly,
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: cnt[NB] | staging[NB][slot_cap] records.
-template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t PPT>
-__global__ void __launch_bounds__(256)
+// LDS: cnt[NB] | staging[NB][slot_cap] records.  NT threads x PPT points each.  With 8-byte records the launch uses
+// 512 x 1 rather than 256 x 2: LDS allows two workgroups per CU either way, and 16 resident waves hide the input loads
+// and the staging round trips far better than 8 (measured 5.6 -> 4.7 ms per step).
+template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t PPT, uint32_t NT>
+__global__ void __launch_bounds__(NT)
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, BinPlan plan) {
@@ -96,12 +98,12 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);
     Rec *staging = reinterpret_cast<Rec *>(cnt + NB);
     const uint32_t ly = blockIdx.y, level = level_base + ly, tile = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < NB; i += 256u) cnt[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) cnt[i] = 0u;
     __syncthreads();
 
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     float *__restrict__ gg = grad_table + (size_t)m.offset * C;
-    const uint32_t b0 = tile * (256u * PPT);
+    const uint32_t b0 = tile * (NT * PPT);
     // merge same-cell runs only where they exist: cells wider than the sample spacing (wave-uniform decision)
     const bool dedup = m.scale * src.sample_spacing() < 0.75f;
 
@@ -114,7 +116,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         constexpr uint32_t MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (uint32_t k = 0; k < PPT; ++k) {
-            const uint32_t b = b0 + k * 256u + threadIdx.x;
+            const uint32_t b = b0 + k * NT + threadIdx.x;
             const bool valid = b < B;
             float x[3], frac[3], g[C];
             uint32_t pg[3];
@@ -180,32 +182,33 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     }
     __syncthreads();
 
-    // B: copy each bucket run to its region.  A wave owns buckets wave, wave+4, ...; it takes them kCopy at a time with
+    // B: copy each bucket run to its region.  A wave owns buckets wave, wave+NW, ...; it takes them kCopy at a time with
     //    straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of several
     //    buckets overlap.  8-byte records travel two per lane as 16-byte LDS reads / global stores (slot_cap even, <= 128).
     const uint32_t wave = threadIdx.x >> 6;
+    constexpr uint32_t NW = NT / 64u;
     if constexpr (sizeof(Rec) == 8) {
         constexpr uint32_t kCopy = 4;
         const uint32_t pairs = CAP >> 1;
         const uint32_t my_pair = min(lane, pairs - 1u);
-        for (uint32_t base = wave; base < NB; base += 4u * kCopy) {
+        for (uint32_t base = wave; base < NB; base += NW * kCopy) {
             uint32_t nrun[kCopy];
             uint4 v[kCopy];
 #pragma unroll
-            for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + 4u * k, NB - 1u)], CAP);
+            for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + NW * k, NB - 1u)], CAP);
 #pragma unroll
             for (uint32_t k = 0; k < kCopy; ++k)
-                v[k] = reinterpret_cast<const uint4 *>(staging + min(base + 4u * k, NB - 1u) * CAP)[my_pair];
+                v[k] = reinterpret_cast<const uint4 *>(staging + min(base + NW * k, NB - 1u) * CAP)[my_pair];
 #pragma unroll
             for (uint32_t k = 0; k < kCopy; ++k) {
-                const uint32_t bkt = base + 4u * k;
+                const uint32_t bkt = base + NW * k;
                 const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
                 if (bkt < NB && 2u * lane < nrun[k]) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // may carry one stale slot: harmless
                 if (bkt < NB && lane == 0u) counts[reg] = nrun[k];
             }
         }
     } else {
-        for (uint32_t bkt = wave; bkt < NB; bkt += 4u) {
+        for (uint32_t bkt = wave; bkt < NB; bkt += NW) {
             const uint32_t n = min(cnt[bkt], CAP);
             const size_t reg = region_index(plan, ly, bkt, tile);
             Rec *__restrict__ dst = regions + reg * CAP;
@@ -246,8 +249,11 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     // LDS atomic (lanes past a run length read slot 0, a line that is fetched anyway -> no extra traffic).
     constexpr uint32_t kGroup = 8;
     // every wave streams ONE contiguous range of tiles (regions of consecutive tiles are adjacent in memory)
-    const uint32_t per_wave = (((plan.n_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
-    const uint32_t t_begin = wave * per_wave, t_end = min(plan.n_tiles, t_begin + per_wave);
+    // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
+    const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
+    const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
+    const uint32_t per_wave = (((split_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
+    const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
         const uint32_t mine = t0 + lane < t_end ? counts[reg0 + t0 + lane] : 0u;
         const uint32_t n_here = min(64u, t_end - t0);
@@ -274,7 +280,9 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
         const uint32_t local = i / C, ch = i - local * C;
         const size_t dst = ((size_t)local << plan.log2_nb) + bucket;
-        gg[dst * C + ch] += (float)ldexp((double)(long long)acc[i], -shift);          // sole owner of these rows
+        const float sum = (float)ldexp((double)(long long)acc[i], -shift);
+        if (gridDim.z == 1u) gg[dst * C + ch] += sum;                                  // sole owner of these rows
+        else atomicAdd(gg + dst * C + ch, sum);                                        // one add per row and split
     }
 }
 

@@ -258,6 +258,29 @@ def test_binned_scatter_equals_atomic_scatter(prec):
     assert float((a - b).abs().max() / a.abs().max()) < 10 * tol
 
 
+def test_binned_scatter_large_batch_split_reducer():
+    """2^18 rays x 128 samples = 33.5 M points: the record buffer holds 6 levels per pass, so the reducer splits every
+    bucket's tiles between two workgroups (gridDim.z = 2, per-row atomics at the end).  Against the atomic scatter."""
+    _abi, encoder, fused, network = _mods()
+    net, _ = _naf_pair(seed=10, log2T=19, scale=0.1)
+    n, S = 1 << 18, 128
+    rays = _rays(n, seed=23).cuda()
+    target = torch.rand(n, device="cuda") * 0.3
+    grads = {}
+    try:
+        for mode in (1, 2):
+            _abi.check(_abi.lib().naf_set_scatter_mode(mode))
+            net.zero_grad()
+            acc = fused.fused_render(rays, net, S, True, seed=3, mlp_precision=_abi.BF16)
+            ((acc - target) ** 2).mean().backward()
+            grads[mode] = net.encoder.embeddings.grad.clone()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    a, b = grads[1].double(), grads[2].double()
+    assert float((a - b).norm() / a.norm()) < 3e-3
+    assert float((a - b).abs().max() / a.abs().max()) < 3e-2
+
+
 def test_foot_config_t22_fp16_table_and_long_rays():
     """foot_50-like shapes (BASELINE.json configs[4]): T=2^22 (wrapped-dense fine levels, 512 scatter buckets), fp16
     table, S=320 -- forward vs the oracle, binned vs atomic gradient."""
