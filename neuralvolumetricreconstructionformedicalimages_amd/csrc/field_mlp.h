@@ -58,7 +58,7 @@ __device__ __forceinline__ float wfrag_value(const float *__restrict__ mlp, uint
 struct PrecBF16 {
     using feat_t = BF16;                      // storage of feature / feature-gradient tensors
     using tr_t = __bf16;                      // element of the LDS transpose image
-    static constexpr uint32_t kTrPitch = 40;  // elements per image row (32 points + pad: conflict-free b128 reads)
+    static constexpr uint32_t kTrPitch = 32;  // elements per image row: [point][32 features], swizzled 8-byte chunks
     static constexpr uint32_t kWFragBytes = 2 * 64 * 16;   // per fragment: 2 K-steps x 64 lanes x 8 bf16
     struct Frag { bf16x8 v[2]; };
 
@@ -89,13 +89,42 @@ struct PrecBF16 {
         fr.v[1] = src[64 + lane];
         return fr;
     }
-    // transpose image: row = feature, col = point
-    static __device__ __forceinline__ void tr_store(tr_t *img, uint32_t row, uint32_t col, float v) { img[row * kTrPitch + col] = (__bf16)v; }
-    // lane (m,h) reads points 8h..8h+7 and 16+8h..16+8h+7 of feature row m  ->  operand with K = points
+    // Transpose image [point][feature], 64-byte rows, read back with ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
+    // A lane writes its four packed 4-slot groups -- slots 4g..4g+3 are features 8g+4h..8g+4h+3 of its point -- as four
+    // 8-byte chunks; chunk c of row n sits at position c ^ ((n >> 1) & 7): the 64 writes of one group then spread over
+    // all 32 write banks (2-way, the minimum for 512 B), and a transposed read takes whole rows, so it stays conflict-free.
+    // `packed` is pack(v): the forward / backward chain has already converted the tile, nothing is converted again.
+    static __device__ __forceinline__ void tr_put(tr_t *img, uint32_t n, uint32_t h, const float (&)[16], const Frag &packed) {
+        unsigned char *row = reinterpret_cast<unsigned char *>(img) + n * 64u;
+        const uint32_t sw = (n >> 1) & 7u;
+        const uint4 lo = __builtin_bit_cast(uint4, packed.v[0]), hi = __builtin_bit_cast(uint4, packed.v[1]);
+        *reinterpret_cast<uint2 *>(row + 8u * ((0u + h) ^ sw)) = make_uint2(lo.x, lo.y);
+        *reinterpret_cast<uint2 *>(row + 8u * ((2u + h) ^ sw)) = make_uint2(lo.z, lo.w);
+        *reinterpret_cast<uint2 *>(row + 8u * ((4u + h) ^ sw)) = make_uint2(hi.x, hi.y);
+        *reinterpret_cast<uint2 *>(row + 8u * ((6u + h) ^ sw)) = make_uint2(hi.z, hi.w);
+    }
+    // Lane (m,h) gets feature m of points 8h..8h+7 (K step 0) and 16+8h..16+8h+7 (K step 1): an operand with K = points.
+    // Per 16-lane group the instruction gathers a block of 4 rows (points) x 16 columns (features); lane 4q+p of the
+    // group supplies the address of row q, columns 4p..4p+3 and lane i receives column i of the four rows.
+    // Must be called by all 64 lanes (EXEC all ones).
     static __device__ __forceinline__ Frag tr_load(const tr_t *img, uint32_t m, uint32_t h) {
+        typedef short v4i16 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+        const uint32_t q = (m >> 2) & 3u, p = m & 3u, chunk = 4u * ((m >> 4) & 1u) + p;
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(img);
         Frag fr;
-        fr.v[0] = *reinterpret_cast<const bf16x8 *>(img + m * kTrPitch + 8u * h);
-        fr.v[1] = *reinterpret_cast<const bf16x8 *>(img + m * kTrPitch + 16u + 8u * h);
+#pragma unroll
+        for (uint32_t s = 0; s < 2; ++s) {
+            v4i16 part[2];
+#pragma unroll
+            for (uint32_t u = 0; u < 2; ++u) {
+                const uint32_t r = 16u * s + 8u * h + 4u * u + q;
+                part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)(base + r * 64u + 8u * (chunk ^ ((r >> 1) & 7u))));
+            }
+            typedef short v8i16 __attribute__((ext_vector_type(8)));
+            const v8i16 both = __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            fr.v[s] = __builtin_bit_cast(bf16x8, both);
+        }
         return fr;
     }
     static __device__ __forceinline__ float frag_sum(const Frag &f) {
@@ -136,7 +165,11 @@ struct PrecF32 {
         for (uint32_t t = 0; t < 16; ++t) fr.v[t] = src[t * 64u + lane];
         return fr;
     }
-    static __device__ __forceinline__ void tr_store(tr_t *img, uint32_t row, uint32_t col, float v) { img[row * kTrPitch + col] = v; }
+    // transpose image: row = feature, col = point (element-wise stores; fp32 has no transposing LDS read)
+    static __device__ __forceinline__ void tr_put(tr_t *img, uint32_t n, uint32_t h, const float (&v)[16], const Frag &) {
+#pragma unroll
+        for (uint32_t t = 0; t < 16; ++t) img[slot_row(t, h) * kTrPitch + n] = v[t];
+    }
     static __device__ __forceinline__ Frag tr_load(const tr_t *img, uint32_t m, uint32_t h) {
         Frag fr;
         const f32x4 *p0 = reinterpret_cast<const f32x4 *>(img + m * kTrPitch + 8u * h);
@@ -195,7 +228,12 @@ __device__ __forceinline__ f32x16 splat_slots(const float (&x)[16]) {
 }
 __device__ __forceinline__ void leaky_inplace(f32x16 &z, float (&out)[16]) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) out[t] = fmaxf(z[t], kLeaky * z[t]);      // slope < 1: max(z, 0.01 z) == LeakyReLU(z), 2 ops
+    for (int t = 0; t < 16; ++t) {        // slope < 1: max(z, 0.01 z) == LeakyReLU(z).  The bare instruction: fmaxf() makes
+        const float zt = z[t], m = kLeaky * zt;   // the compiler canonicalise z first (a third VALU op per element)
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(zt), "v"(m));
+        out[t] = r;
+    }
 }
 
 // final activation and its derivative expressed through the OUTPUT y (network.py:23-32)

@@ -127,11 +127,8 @@ struct F16 { using store_t = _Float16; };
 struct BF16 { using store_t = uint16_t; };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even, NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 
 template <typename T> struct Conv;

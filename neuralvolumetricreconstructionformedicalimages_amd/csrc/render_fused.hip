@@ -23,20 +23,52 @@ namespace naf {
 
 // ---- feature tile I/O ------------------------------------------------------------------------------------
 // Lane (n,h) owns features f = 8q + 4h + i (q,i = 0..3) of point p; feature f is channel f % C of level f / C.
+// The load is split in two so that a kernel can issue the (raw) loads of its NEXT tile before it starts the arithmetic of
+// the current one and convert them an iteration later: the MLP kernels run at one or two waves per SIMD, nothing else
+// hides the ~2 us HBM round trip.
+template <uint32_t kBytes> struct RawWord;
+template <> struct RawWord<2> { typedef uint16_t type; };
+template <> struct RawWord<4> { typedef uint32_t type; };
+template <> struct RawWord<8> { typedef uint2 type; };
+template <> struct RawWord<16> { typedef uint4 type; };
+
 template <typename FT, uint32_t C>
-__device__ __forceinline__ void load_feat_slots(const typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
-                                                uint32_t h, float (&x)[16]) {
-    constexpr uint32_t V = C < 4 ? C : 4;     // contiguous channels per access
+struct FeatRaw {
+    static constexpr uint32_t V = C < 4 ? C : 4;     // contiguous channels per access
+    using word_t = typename RawWord<V * sizeof(typename FT::store_t)>::type;
+    word_t w[16 / V];
+};
+template <typename FT, uint32_t C>
+__device__ __forceinline__ void load_feat_raw(const typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
+                                              uint32_t h, FeatRaw<FT, C> &raw) {
+    constexpr uint32_t V = FeatRaw<FT, C>::V;
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q)
 #pragma unroll
         for (uint32_t i = 0; i < 4; i += V) {
             const uint32_t f = 8u * q + 4u * h + i;
-            float v[V];
-            load_vec<FT, V>(feat + ((size_t)(f / C) * B + p) * C + (f % C), v);
-#pragma unroll
-            for (uint32_t k = 0; k < V; ++k) x[4 * q + i + k] = v[k];
+            raw.w[(4 * q + i) / V] =
+                *reinterpret_cast<const typename FeatRaw<FT, C>::word_t *>(feat + ((size_t)(f / C) * B + p) * C + (f % C));
         }
+}
+template <typename FT, uint32_t C>
+__device__ __forceinline__ void unpack_feat_raw(const FeatRaw<FT, C> &raw, float (&x)[16]) {
+    constexpr uint32_t V = FeatRaw<FT, C>::V;
+    using S = typename FT::store_t;
+#pragma unroll
+    for (uint32_t j = 0; j < 16 / V; ++j) {
+        S e[V];
+        __builtin_memcpy(e, &raw.w[j], sizeof(e));
+#pragma unroll
+        for (uint32_t k = 0; k < V; ++k) x[V * j + k] = Conv<FT>::load(&e[k]);
+    }
+}
+template <typename FT, uint32_t C>
+__device__ __forceinline__ void load_feat_slots(const typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
+                                                uint32_t h, float (&x)[16]) {
+    FeatRaw<FT, C> raw;
+    load_feat_raw<FT, C>(feat, B, p, h, raw);
+    unpack_feat_raw<FT, C>(raw, x);
 }
 template <typename FT, uint32_t C>
 __device__ __forceinline__ void store_feat_slots(typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t p,
@@ -97,6 +129,8 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
         const uint32_t S = src.S, tiles = (S + 31u) / 32u;
         const bool use_zbuf = S <= kMaxSamplesLds;
         float *zbuf = reinterpret_cast<float *>(smem + ((MlpShared<P>::kBytes + 15u) & ~15u)) + (threadIdx.x >> 6) * kMaxSamplesLds;
+        FeatRaw<typename P::feat_t, C> ahead;                 // features of the next tile, in flight during this one
+        if (wave < n_items) load_feat_raw<typename P::feat_t, C>(feat, B, wave * S + min(n, S - 1u), h, ahead);
         for (uint32_t r = wave; r < n_items; r += n_waves) {
             const float *ray = src.rays + (size_t)r * 8;
             const float near = ray[6], far = ray[7];
@@ -106,8 +140,14 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
             for (uint32_t k = 0; k < tiles; ++k) {
                 const uint32_t s = 32u * k + n;
                 const bool valid = s < S;
-                const uint32_t p = r * S + (valid ? s : S - 1u);
-                load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
+                const FeatRaw<typename P::feat_t, C> now = ahead;
+                {   // next tile of this ray, else first tile of this wave's next ray, else (nothing left) this tile again
+                    const bool more = k + 1u < tiles;
+                    const uint32_t rn = more ? r : (r + n_waves < n_items ? r + n_waves : r);
+                    const uint32_t sn = more ? s + 32u : n;
+                    load_feat_raw<typename P::feat_t, C>(feat, B, rn * S + min(sn, S - 1u), h, ahead);
+                }
+                unpack_feat_raw<typename P::feat_t, C>(now, x0);
                 const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
                 const float sigma = last_act(act, z4);
                 if (valid && h == 0)
@@ -171,6 +211,8 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
     Sh::slot_vector(smem, 3, h, w3s);
 
     const uint32_t S = src.S, tiles = (S + 31u) / 32u;
+    FeatRaw<typename P::feat_t, C> ahead;                     // features of the next tile, in flight during this one
+    if (wave < n_rays) load_feat_raw<typename P::feat_t, C>(feat, B, wave * S + min(n, S - 1u), h, ahead);
     for (uint32_t r = wave; r < n_rays; r += n_waves) {
         const float *ray = src.rays + (size_t)r * 8;
         const float near = ray[6], far = ray[7];
@@ -184,7 +226,14 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             const uint32_t p = r * S + (valid ? s : S - 1u);
             float x0[16], h1[16], h2[16], h3[16];
             typename P::Frag x0f;
-            load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
+            const FeatRaw<typename P::feat_t, C> now = ahead;
+            {   // next tile of this ray, else first tile of this wave's next ray, else (nothing left) this tile again
+                const bool more = k + 1u < tiles;
+                const uint32_t rn = more ? r : (r + n_waves < n_rays ? r + n_waves : r);
+                const uint32_t sn = more ? s + 32u : n;
+                load_feat_raw<typename P::feat_t, C>(feat, B, rn * S + min(sn, S - 1u), h, ahead);
+            }
+            unpack_feat_raw<typename P::feat_t, C>(now, x0);
             const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
             const float sigma = last_act(act, z4);
             const float gsig = !valid ? 0.0f
@@ -200,14 +249,11 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             }
             if (h == 0) db3 += g4;
 
-            // transpose G3, X0, H2 through LDS: image row = feature, column = point of the tile
-#pragma unroll
-            for (uint32_t t = 0; t < 16; ++t) {
-                const uint32_t row = slot_row(t, h);
-                P::tr_store(imgA, row, n, g[t]);
-                P::tr_store(imgB, row, n, x0[t]);
-                P::tr_store(imgC, row, n, h2[t]);
-            }
+            // transpose G3, X0, H2 through LDS (P::tr_put / P::tr_load): the weight gradients contract over points
+            const typename P::Frag g3f = P::pack(g);
+            P::tr_put(imgA, n, h, g, g3f);
+            P::tr_put(imgB, n, h, x0, x0f);
+            P::tr_put(imgC, n, h, h2, P::pack(h2));
             wave_lds_fence<P>();
             typename P::Frag gA = P::tr_load(imgA, n, h);             // A[m = out][k = point]
             const typename P::Frag xB = P::tr_load(imgB, n, h);        // B[k = point][n = in]
@@ -218,19 +264,15 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             wave_lds_fence<P>();
 
             // back through layer 2 (skip layer): d[input] and d[h2]
-            const typename P::Frag g3f = P::pack(g);
             f32x16 zero = {0};
             f32x16 dx0 = P::mma(P::load_wfrag(smem, kFW2aT, lane), g3f, zero);
             f32x16 dh = P::mma(P::load_wfrag(smem, kFW2bT, lane), g3f, zero);
 #pragma unroll
             for (int t = 0; t < 16; ++t) g[t] = dh[t] * (h2[t] > 0.0f ? 1.0f : kLeaky);      // G2
 
-#pragma unroll
-            for (uint32_t t = 0; t < 16; ++t) {
-                const uint32_t row = slot_row(t, h);
-                P::tr_store(imgA, row, n, g[t]);
-                P::tr_store(imgC, row, n, h1[t]);
-            }
+            const typename P::Frag g2f = P::pack(g);
+            P::tr_put(imgA, n, h, g, g2f);
+            P::tr_put(imgC, n, h, h1, P::pack(h1));
             wave_lds_fence<P>();
             gA = P::tr_load(imgA, n, h);
             hB = P::tr_load(imgC, n, h);
@@ -238,18 +280,18 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             db1 += P::frag_sum(gA);
             wave_lds_fence<P>();
 
-            dh = P::mma(P::load_wfrag(smem, kFW1T, lane), P::pack(g), zero);
+            dh = P::mma(P::load_wfrag(smem, kFW1T, lane), g2f, zero);
 #pragma unroll
             for (int t = 0; t < 16; ++t) g[t] = dh[t] * (h1[t] > 0.0f ? 1.0f : kLeaky);      // G1
-#pragma unroll
-            for (uint32_t t = 0; t < 16; ++t) P::tr_store(imgA, slot_row(t, h), n, g[t]);
+            const typename P::Frag g1f = P::pack(g);
+            P::tr_put(imgA, n, h, g, g1f);
             wave_lds_fence<P>();
             gA = P::tr_load(imgA, n, h);
             dW0 = P::mma(gA, xB, dW0);
             db0 += P::frag_sum(gA);
             wave_lds_fence<P>();
 
-            dx0 = P::mma(P::load_wfrag(smem, kFW0T, lane), P::pack(g), dx0);
+            dx0 = P::mma(P::load_wfrag(smem, kFW0T, lane), g1f, dx0);
             if (valid) {
                 float o[16];
 #pragma unroll
