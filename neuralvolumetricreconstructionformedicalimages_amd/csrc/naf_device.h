@@ -180,8 +180,19 @@ __device__ __forceinline__ void store_vec(typename T::store_t *p, const float (&
     using S = typename T::store_t;
     constexpr uint32_t bytes = C * sizeof(S);
     S e[C];
+    if constexpr (sizeof(S) == 2 && C % 2 == 0 && !__is_same(S, _Float16)) {   // bf16: one v_cvt_pk_bf16_f32 per pair
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (uint32_t c = 0; c < C; ++c) Conv<T>::store(&e[c], v[c]);
+        for (uint32_t c = 0; c < C; c += 2) {
+            bf16x2 pk;
+            pk[0] = (__bf16)v[c];
+            pk[1] = (__bf16)v[c + 1];
+            __builtin_memcpy(&e[c], &pk, 4);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) Conv<T>::store(&e[c], v[c]);
+    }
     if constexpr (bytes == 2) { *p = e[0]; }
     else if constexpr (bytes == 4) { uint32_t raw; __builtin_memcpy(&raw, e, 4); *reinterpret_cast<uint32_t *>(p) = raw; }
     else if constexpr (bytes == 8) { uint2 raw; __builtin_memcpy(&raw, e, 8); *reinterpret_cast<uint2 *>(p) = raw; }

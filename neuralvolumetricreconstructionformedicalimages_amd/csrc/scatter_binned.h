@@ -57,7 +57,7 @@ struct RecBF16 {                      // row + C bf16 values (packed two per dwo
 };
 
 struct BinPlan {
-    uint32_t tile_points;     // points per pass-1 workgroup = NT * PPT
+    uint32_t tile_points;     // points per pass-1 workgroup (= its thread count)
     uint32_t n_tiles;
     uint32_t log2_nb;         // NB = buckets per level
     uint32_t slot_cap;        // records per (level, bucket, tile) region = LDS slots per bucket in pass 1
@@ -85,61 +85,72 @@ __device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly,
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: cnt[NB] | staging[NB][slot_cap] records.  NT threads x PPT points each.  With 8-byte records the launch uses
-// 512 x 1 rather than 256 x 2: LDS allows two workgroups per CU either way, and 16 resident waves hide the input loads
-// and the staging round trips far better than 8 (measured 5.6 -> 4.7 ms per step).
-template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t PPT, uint32_t NT>
+// LDS: cnt[2][NB] | staging[NB][slot_cap] records.  One workgroup = one tile of NT points (one per thread) x LV
+// consecutive levels: the sample position is evaluated once, and the stores of one level drain while the next level
+// is being computed.  With 8-byte records the launch uses NT = 512: LDS allows two or three workgroups per CU either
+// way, and 16+ resident waves hide the input loads and the staging round trips far better than 8 (5.6 -> 4.7 ms/step).
+template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t LV>
 __global__ void __launch_bounds__(NT)
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
-                   uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, BinPlan plan) {
+                   uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
+                   BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NW = NT / 64u;
     const uint32_t NB = 1u << plan.log2_nb, mask = NB - 1u, CAP = plan.slot_cap;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);
-    Rec *staging = reinterpret_cast<Rec *>(cnt + NB);
-    const uint32_t ly = blockIdx.y, level = level_base + ly, tile = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < NB; i += NT) cnt[i] = 0u;
+    uint32_t *cnt2 = reinterpret_cast<uint32_t *>(smem);
+    Rec *staging = reinterpret_cast<Rec *>(cnt2 + 2u * NB);
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 2u * NB; i += NT) cnt2[i] = 0u;
+
+    // the thread's point.  Threads past the end of the batch take the last point with a zero gradient: their records
+    // add nothing, and no validity test is needed further down.
+    const uint32_t b_raw = tile * NT + threadIdx.x;
+    const bool valid = b_raw < B;
+    const uint32_t b = valid ? b_raw : B - 1u;
+    float x[3];
+    src.get(b, x);
+    const float spacing = src.sample_spacing();
     __syncthreads();
 
-    const LevelMeta m = make_level_meta<3>(offsets, level, H);
-    float *__restrict__ gg = grad_table + (size_t)m.offset * C;
-    const uint32_t b0 = tile * (NT * PPT);
-    // merge same-cell runs only where they exist: cells wider than the sample spacing (wave-uniform decision)
-    const bool dedup = m.scale * src.sample_spacing() < 0.75f;
+    for (uint32_t it = 0; it < LV; ++it) {
+        const uint32_t ly = blockIdx.y * LV + it;
+        if (ly >= n_levels) break;                                   // uniform
+        const uint32_t level = level_base + ly;
+        uint32_t *cnt = cnt2 + (it & 1u) * NB;
+        const LevelMeta m = make_level_meta<3>(offsets, level, H);
+        float *__restrict__ gg = grad_table + (size_t)m.offset * C;
 
-    // A: rows + values of this thread's contributions
-    uint32_t row[PPT][8];
-    float val[PPT][8][C];
-    uint64_t cell[PPT];
-    const uint32_t lane = threadIdx.x & 63u;
-    dispatch_mode(m.mode, [&](auto mode_tag) {
-        constexpr uint32_t MODE = decltype(mode_tag)::value;
+        // A: rows + values of this thread's eight contributions
+        uint32_t row[8];
+        float val[8][C];
+        float frac[3], g[C];
+        uint32_t pg[3];
+        locate<3>(x, m.scale, frac, pg);
+        load_vec<FT, C>(grad + ((size_t)level * B + b) * C, g);
+        if (!valid) {
 #pragma unroll
-        for (uint32_t k = 0; k < PPT; ++k) {
-            const uint32_t b = b0 + k * NT + threadIdx.x;
-            const bool valid = b < B;
-            float x[3], frac[3], g[C];
-            uint32_t pg[3];
-            src.get(valid ? b : B - 1u, x);
-            locate<3>(x, m.scale, frac, pg);
-            load_vec<FT, C>(grad + ((size_t)level * B + (valid ? b : B - 1u)) * C, g);
-            cell[k] = valid ? ((uint64_t)pg[0] | ((uint64_t)pg[1] << 21) | ((uint64_t)pg[2] << 42)) : ~0ull;
+            for (uint32_t ch = 0; ch < C; ++ch) g[ch] = 0.0f;
+        }
+        dispatch_mode(m.mode, [&](auto mode_tag) {
+            constexpr uint32_t MODE = decltype(mode_tag)::value;
 #pragma unroll
             for (uint32_t c = 0; c < 8; ++c) {
                 uint32_t pl[3];
                 const float w = corner<3>(c, frac, pg, pl);
-                row[k][c] = valid ? grid_row<MODE, 3>(m, pl) : 0xffffffffu;
+                row[c] = grid_row<MODE, 3>(m, pl);
 #pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) val[k][c][ch] = w * g[ch];
+                for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w * g[ch];
             }
-        }
-    });
-    if (dedup) {
-        // Consecutive samples of a ray that fall into the same cell hit the same 8 rows: merge each run of equal
-        // cells inside the wave (segmented inclusive scan); only the last lane of a run emits records.
-        for (uint32_t k = 0; k < PPT; ++k) {
-            const uint64_t prev = __shfl_up(cell[k], 1, 64);
-            const uint64_t heads = __ballot(lane == 0u || cell[k] != prev);
+        });
+        // Cells wider than the sample spacing (wave-uniform decision): consecutive samples of a ray that fall into the
+        // same cell hit the same 8 rows.  Merge each run of equal cells inside the wave (segmented inclusive scan);
+        // only the last lane of a run emits records.
+        bool emit = true;
+        if (m.scale * spacing < 0.75f) {
+            const uint64_t cell = (uint64_t)pg[0] | ((uint64_t)pg[1] << 21) | ((uint64_t)pg[2] << 42);
+            const uint64_t prev = __shfl_up(cell, 1, 64);
+            const uint64_t heads = __ballot(lane == 0u || cell != prev);
             const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
 #pragma unroll
             for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -148,73 +159,67 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) {
-                        const float t = __shfl_up(val[k][c][ch], d, 64);
-                        if (take) val[k][c][ch] += t;
+                        const float t = __shfl_up(val[c][ch], d, 64);
+                        if (take) val[c][ch] += t;
                     }
             }
-            const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
-            if (!tail) {
+            emit = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+        }
+        // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
+        if (emit) {
+            uint32_t pos[8];
 #pragma unroll
-                for (uint32_t c = 0; c < 8; ++c) row[k][c] = 0xffffffffu;
+            for (uint32_t c = 0; c < 8; ++c) pos[c] = atomicAdd(&cnt[row[c] & mask], 1u);
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) {
+                if (pos[c] < CAP) {
+                    Rec r;
+                    r.set(row[c] >> plan.log2_nb, val[c]);
+                    staging[(row[c] & mask) * CAP + pos[c]] = r;
+                } else {
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[c] * C + ch, val[c][ch]);
+                    atomicAdd(overflow, 1u);
+                }
             }
         }
-    }
-    // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
-#pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k) {
-        uint32_t pos[8];
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            pos[c] = row[k][c] != 0xffffffffu ? atomicAdd(&cnt[row[k][c] & mask], 1u) : 0xffffffffu;
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c) {
-            if (pos[c] == 0xffffffffu) continue;
-            if (pos[c] < CAP) {
-                Rec r;
-                r.set(row[k][c] >> plan.log2_nb, val[k][c]);
-                staging[(row[k][c] & mask) * CAP + pos[c]] = r;
-            } else {
-#pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[k][c] * C + ch, val[k][c][ch]);
-                atomicAdd(overflow, 1u);
-            }
-        }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // B: copy each bucket run to its region.  A wave owns buckets wave, wave+NW, ...; it takes them kCopy at a time with
-    //    straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of several
-    //    buckets overlap.  8-byte records travel two per lane as 16-byte LDS reads / global stores (slot_cap even, <= 128).
-    const uint32_t wave = threadIdx.x >> 6;
-    constexpr uint32_t NW = NT / 64u;
-    if constexpr (sizeof(Rec) == 8) {
-        constexpr uint32_t kCopy = 4;
-        const uint32_t pairs = CAP >> 1;
-        const uint32_t my_pair = min(lane, pairs - 1u);
-        for (uint32_t base = wave; base < NB; base += NW * kCopy) {
-            uint32_t nrun[kCopy];
-            uint4 v[kCopy];
+        // B: copy each bucket run to its region.  A wave owns buckets wave, wave+NW, ...; it takes them kCopy at a time
+        //    with straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of
+        //    several buckets overlap.  8-byte records travel two per lane as 16-byte LDS reads / global stores
+        //    (slot_cap even, <= 128).  The other counter set is cleared for the next level meanwhile.
+        for (uint32_t i = threadIdx.x; i < NB; i += NT) cnt2[((it & 1u) ^ 1u) * NB + i] = 0u;
+        if constexpr (sizeof(Rec) == 8) {
+            constexpr uint32_t kCopy = 4;
+            const uint32_t pairs = CAP >> 1;
+            const uint32_t my_pair = min(lane, pairs - 1u);
+            for (uint32_t base = wave; base < NB; base += NW * kCopy) {
+                uint32_t nrun[kCopy];
+                uint4 v[kCopy];
 #pragma unroll
-            for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + NW * k, NB - 1u)], CAP);
+                for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + NW * k, NB - 1u)], CAP);
 #pragma unroll
-            for (uint32_t k = 0; k < kCopy; ++k)
-                v[k] = reinterpret_cast<const uint4 *>(staging + min(base + NW * k, NB - 1u) * CAP)[my_pair];
+                for (uint32_t k = 0; k < kCopy; ++k)
+                    v[k] = reinterpret_cast<const uint4 *>(staging + min(base + NW * k, NB - 1u) * CAP)[my_pair];
 #pragma unroll
-            for (uint32_t k = 0; k < kCopy; ++k) {
-                const uint32_t bkt = base + NW * k;
-                const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
-                if (bkt < NB && 2u * lane < nrun[k]) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // may carry one stale slot: harmless
-                if (bkt < NB && lane == 0u) counts[reg] = nrun[k];
+                for (uint32_t k = 0; k < kCopy; ++k) {
+                    const uint32_t bkt = base + NW * k;
+                    const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
+                    if (bkt < NB && 2u * lane < nrun[k]) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // may carry one stale slot: harmless
+                    if (bkt < NB && lane == 0u) counts[reg] = nrun[k];
+                }
+            }
+        } else {
+            for (uint32_t bkt = wave; bkt < NB; bkt += NW) {
+                const uint32_t n = min(cnt[bkt], CAP);
+                const size_t reg = region_index(plan, ly, bkt, tile);
+                Rec *__restrict__ dst = regions + reg * CAP;
+                for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
+                if (lane == 0u) counts[reg] = n;
             }
         }
-    } else {
-        for (uint32_t bkt = wave; bkt < NB; bkt += NW) {
-            const uint32_t n = min(cnt[bkt], CAP);
-            const size_t reg = region_index(plan, ly, bkt, tile);
-            Rec *__restrict__ dst = regions + reg * CAP;
-            for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
-            if (lane == 0u) counts[reg] = n;
-        }
+        __syncthreads();                                             // staging and this counter set are free again
     }
 }
 

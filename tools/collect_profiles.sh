@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects the evidence kept under profiles/ on the GPU box (run through gpurun from the repo root):
+#   rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE counter passes (separate runs), the default bench line, a batch
+#   sweep, the fp32 mode and the per-level split.  Everything lands in gpurun_out/prof/; tools/install_profiles.py copies
+#   the summaries into profiles/.
+set -e
+export TMPDIR=/tmp
+OUT=gpurun_out/prof
+rm -rf $OUT && mkdir -p $OUT
+ARGS="--steps 10 --warmup 2 --rays 65536 --cpu-seconds 0"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+echo stats done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_fetch.json 2> $OUT/fetch.err
+echo fetch done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_write.json 2> $OUT/write.err
+echo write done
+timeout -k 10 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo default done
+for r in 1024 4096 16384 65536 262144 1048576; do
+  timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays $r --cpu-seconds 0 >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
+done
+echo sweep done
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
+NAF_PROFILE_LEVELS=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
+echo all done
+find $OUT -name "*.csv" | head -20
