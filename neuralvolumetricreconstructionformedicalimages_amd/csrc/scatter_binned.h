@@ -252,7 +252,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
     // kGroup at a time with straight-line code: 2*kGroup unconditional loads per lane are in flight before the first
     // LDS atomic (lanes past a run length read slot 0, a line that is fetched anyway -> no extra traffic).
-    constexpr uint32_t kGroup = 8;
+    constexpr uint32_t kGroup = 8, kTail = 16;
     // every wave streams ONE contiguous range of tiles (regions of consecutive tiles are adjacent in memory)
     // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
     const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
@@ -263,20 +263,46 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         const uint32_t mine = t0 + lane < t_end ? counts[reg0 + t0 + lane] : 0u;
         const uint32_t n_here = min(64u, t_end - t0);
         for (uint32_t j = 0; j < n_here; j += kGroup) {
-            uint32_t n[kGroup];
-            Rec ra[kGroup], rb[kGroup];
+            uint32_t n[kGroup], n_max = 0u;
+            Rec ra[kGroup];
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) {
                 const uint32_t tj = min(j + u, n_here - 1u);
                 n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
-                const Rec *__restrict__ src_r = regions + (reg0 + t0 + tj) * CAP;
-                ra[u] = src_r[lane < n[u] ? lane : 0u];
-                rb[u] = src_r[lane + 64u < n[u] ? lane + 64u : 0u];
+                n_max = max(n_max, n[u]);
+                ra[u] = (regions + (reg0 + t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
             }
+            if (__builtin_amdgcn_readfirstlane(n_max) <= 64u + kTail) {
+                // the usual case: no run is longer than 64 + kTail records.  The tails (records 64..) of 64 / kTail regions
+                // share one load and one pair of LDS atomics, kTail lanes per region, instead of a nearly empty wave each.
+                constexpr uint32_t kPer = 64u / kTail;                      // regions per tail instruction
+                Rec rt[kGroup / kPer];
+                uint32_t nt[kGroup / kPer];
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) {
-                if (lane < n[u]) add(ra[u]);                            // slot_cap <= 128 (planner invariant): two loads
-                if (lane + 64u < n[u]) add(rb[u]);                      // per lane cover a whole region
+                for (uint32_t q = 0; q < kGroup / kPer; ++q) {
+                    const uint32_t u = q * kPer + lane / kTail, slot = 64u + (lane % kTail);
+                    const uint32_t tj = min(j + u, n_here - 1u);
+                    nt[q] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
+                    rt[q] = (regions + (reg0 + t0 + tj) * CAP)[slot < nt[q] ? slot : 0u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    if (lane < n[u]) add(ra[u]);
+#pragma unroll
+                for (uint32_t q = 0; q < kGroup / kPer; ++q)
+                    if (64u + (lane % kTail) < nt[q]) add(rt[q]);
+            } else {
+                Rec rb[kGroup];                                             // slot_cap <= 128 (planner invariant): two loads
+#pragma unroll                                                              // per lane cover a whole region
+                for (uint32_t u = 0; u < kGroup; ++u) {
+                    const uint32_t tj = min(j + u, n_here - 1u);
+                    rb[u] = (regions + (reg0 + t0 + tj) * CAP)[lane + 64u < n[u] ? lane + 64u : 0u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u) {
+                    if (lane < n[u]) add(ra[u]);
+                    if (lane + 64u < n[u]) add(rb[u]);
+                }
             }
         }
     }
