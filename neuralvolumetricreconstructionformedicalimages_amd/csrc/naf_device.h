@@ -203,6 +203,40 @@ __device__ __forceinline__ void store_vec(typename T::store_t *p, const float (&
     }
 }
 
+// A load whose conversion to fp32 is deferred: the raw words can cross a barrier / a block of stores before anything waits
+// for them (s_waitcnt is placed at the first use, and vmcnt retires in order, so issue order matters).
+template <typename T, uint32_t C>
+struct RawVec {
+    static constexpr uint32_t kBytes = C * sizeof(typename T::store_t);
+    uint32_t w[(kBytes + 3) / 4];
+};
+template <typename T, uint32_t C>
+__device__ __forceinline__ void raw_load(const typename T::store_t *p, RawVec<T, C> &r) {
+    constexpr uint32_t bytes = RawVec<T, C>::kBytes;
+    if constexpr (bytes == 2) r.w[0] = *reinterpret_cast<const uint16_t *>(p);
+    else if constexpr (bytes == 4) r.w[0] = *reinterpret_cast<const uint32_t *>(p);
+    else if constexpr (bytes == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(p); r.w[0] = v.x; r.w[1] = v.y; }
+    else {
+#pragma unroll
+        for (uint32_t i = 0; i < bytes / 16; ++i) {
+            const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+            r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+        }
+    }
+}
+template <typename T, uint32_t C>
+__device__ __forceinline__ void raw_unpack(const RawVec<T, C> &r, float (&v)[C]) {
+    using S = typename T::store_t;
+    S e[C];
+    __builtin_memcpy(e, r.w, C * sizeof(S));
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) v[c] = Conv<T>::load(&e[c]);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, i.e.
+// s_waitcnt vmcnt(0): every wave would sit out the round trip of the global stores it has just issued.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- counter-based jitter (used when the caller passes no t_rand) --------------------------------
 // Two rounds of the "lowbias32" integer finaliser over (seed, global ray index, sample); 24 bits -> [0,1).
 // 32-bit only on purpose: it is re-evaluated by every kernel that needs the sample position.

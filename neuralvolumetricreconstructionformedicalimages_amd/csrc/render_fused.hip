@@ -12,6 +12,7 @@
 //   4 hash_backward_kernel<SrcRays>  dfeat -> grad table (fp32 atomics)
 //   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=)
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "naf_host.h"
@@ -430,11 +431,12 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
     const uint32_t slot_mean = std::max<uint32_t>(1u, (tile * 8u) >> log2_nb);
-    // 1.5 x mean + 8: the Poisson tail beyond it is < 1e-4 (overflow is still correct, just slower); even; <= 128 because the
-    // reducer reads a region with two loads per lane.  For 512-point tiles this is 104 slots = 832 B = 13 x 64 B per region:
-    // an odd multiple of 64 B spreads consecutive regions over the memory channels (measured bin time per step with 96 /
-    // 104 / 112 / 128 slots: 4.84 / 4.69 / 5.52 / 5.47 ms).
-    plan->slot_cap = std::min(128u, (slot_mean + slot_mean / 2u + 8u + 1u) & ~1u);
+    // mean + 4 sigma of the (near-Poisson) run length: the tail beyond it is ~3e-5 per run, and an overflowing record is
+    // still correct (global atomic), just slower.  <= 128 because the reducer reads a region with two loads per lane.
+    // 8-byte records: a multiple of 16 slots, so regions start on 128-byte lines and pass 1 writes whole lines only --
+    // HBM takes ragged 16-byte-granular runs at ~3 TB/s but line-aligned ones at > 5 TB/s (tools/write_pattern_bench.hip).
+    const uint32_t want = slot_mean + (uint32_t)std::ceil(4.0 * std::sqrt((double)slot_mean));
+    plan->slot_cap = std::min(128u, record_bytes(cfg) == 8 ? (want + 15u) & ~15u : (want + 1u) & ~1u);
     plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
     const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));

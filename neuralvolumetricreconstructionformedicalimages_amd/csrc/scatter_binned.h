@@ -7,15 +7,22 @@
 // A level of the table gets ~50-200 contributions per row per step, but they are hash-scattered, so no locality trick
 // removes them -- they have to be ROUTED to an owner instead (a one-digit radix multisplit on the row index):
 //
-//   pass 1  bin      one workgroup = one tile of points x one level.  It counts its contributions per bucket
-//                    (bucket = row & (NB-1)) in LDS, reserves a contiguous range in each bucket's global stream with ONE
-//                    returning atomic per non-empty bucket, counting-sorts the records (row, w*g[0..C)) in LDS and
-//                    copies them out in bucket order, so stores are coalesced runs instead of 64 scattered 8-byte
-//                    pieces per wave.  A full stream falls back to a global atomic for that contribution, so any
-//                    capacity is CORRECT; streams are sized 1.25x the uniform expectation.
-//   pass 2  reduce   one workgroup = one (bucket, level): streams its records (contiguous, coalesced, several loads
-//                    in flight per lane), accumulates rows  row >> log2(NB)  in LDS (ds_add_f32), then adds the finished
-//                    rows to the gradient table with plain read-modify-writes -- it is the only owner of those rows.
+//   pass 1  bin      one workgroup = one tile of 512 points x up to four consecutive levels.  Per level every thread takes
+//                    an LDS slot for each of its 8 contributions in the bucket's staging run (bucket = row & (NB-1), one
+//                    returning LDS atomic per record) and writes the record (row >> log2 NB, w*g[0..C)) there; the runs are
+//                    then copied to fixed-size global REGIONS [level][tile][bucket][slot_cap] with 16-byte stores that
+//                    cover whole 128-byte lines, and the run lengths go to counts[level][bucket][tile].  No global
+//                    atomics, no prefix sums between workgroups; a run that outgrows its region (~3e-5 of them) falls
+//                    back to global atomics for the excess, so any capacity is CORRECT.
+//   pass 2  reduce   one workgroup = one (bucket, level): streams the bucket's regions of all tiles (several loads in
+//                    flight per lane), accumulates rows  row >> log2(NB)  in LDS as 64-bit fixed point (ds_add_u64), then
+//                    adds the finished rows to the gradient table with plain read-modify-writes -- it is the only owner
+//                    of those rows.
+//
+// What the memory system wants (tools/write_pattern_bench.hip, MI355X): the 64 runs of a tile written next to each other
+// ([tile][bucket] order) and line-aligned at both ends reach > 5 TB/s; the same bytes as ragged 16-byte-granular runs, or
+// [bucket][tile] order at a 768-byte stride, only ~3 TB/s.  Waves never wait for these stores: the barriers inside the
+// level loop order LDS traffic only (lds_barrier), and the one global load of the loop is consumed before the stores.
 //
 // Bucket = LOW bits of the row, so dense coarse levels (whose rows are spatially ordered and heavily skewed toward the
 // volume centre) spread as evenly as the hashed ones.
@@ -80,8 +87,12 @@ __device__ __forceinline__ long long to_fixed(float v, double scale) {
     return __double_as_longlong(d) - 0x4338000000000000ll;
 }
 
-__device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
+// run lengths: [level][bucket][tile] (one coalesced load per 64 tiles in pass 2); records: [level][tile][bucket][slot_cap]
+__device__ __forceinline__ size_t count_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
     return (((size_t)ly << plan.log2_nb) + bucket) * plan.n_tiles + tile;
+}
+__device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
+    return ((((size_t)ly * plan.n_tiles) + tile) << plan.log2_nb) + bucket;
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
@@ -111,6 +122,11 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     float x[3];
     src.get(b, x);
     const float spacing = src.sample_spacing();
+    // this level's feature gradient, requested one level ahead (see the note at the copy-out)
+    RawVec<FT, C> graw;
+    float g[C];
+    if (blockIdx.y * LV < n_levels) raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + b) * C, graw);
+    raw_unpack<FT, C>(graw, g);
     __syncthreads();
 
     for (uint32_t it = 0; it < LV; ++it) {
@@ -124,10 +140,9 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         // A: rows + values of this thread's eight contributions
         uint32_t row[8];
         float val[8][C];
-        float frac[3], g[C];
+        float frac[3];
         uint32_t pg[3];
         locate<3>(x, m.scale, frac, pg);
-        load_vec<FT, C>(grad + ((size_t)level * B + b) * C, g);
         if (!valid) {
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ++ch) g[ch] = 0.0f;
@@ -183,7 +198,14 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 }
             }
         }
-        __syncthreads();
+        // The next level's gradient is requested here and CONSUMED right after the barrier, before this level's stores are
+        // issued: vmcnt retires in order and the compiler can only wait for "everything", so any wait placed after the stores
+        // would sit out their whole round trip.  This way the stores drain behind the next level's arithmetic.
+        if (it + 1u < LV && ly + 1u < n_levels) raw_load<FT, C>(grad + ((size_t)(level + 1u) * B + b) * C, graw);
+        lds_barrier();
+        raw_unpack<FT, C>(graw, g);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) asm volatile("" : "+v"(g[ch]) : : "memory");      // pin the wait here
 
         // B: copy each bucket run to its region.  A wave owns buckets wave, wave+NW, ...; it takes them kCopy at a time
         //    with straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of
@@ -193,7 +215,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         if constexpr (sizeof(Rec) == 8) {
             constexpr uint32_t kCopy = 4;
             const uint32_t pairs = CAP >> 1;
-            const uint32_t my_pair = min(lane, pairs - 1u);
+            const uint32_t my_pair = min(lane, pairs - 1u);     // (slot_cap is a multiple of 16 records = 128 B here)
             for (uint32_t base = wave; base < NB; base += NW * kCopy) {
                 uint32_t nrun[kCopy];
                 uint4 v[kCopy];
@@ -206,8 +228,8 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 for (uint32_t k = 0; k < kCopy; ++k) {
                     const uint32_t bkt = base + NW * k;
                     const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
-                    if (bkt < NB && 2u * lane < nrun[k]) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // may carry one stale slot: harmless
-                    if (bkt < NB && lane == 0u) counts[reg] = nrun[k];
+                    if (bkt < NB && 2u * lane < min((nrun[k] + 15u) & ~15u, CAP)) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // whole 128-byte lines; stale slots are harmless
+                    if (bkt < NB && lane == 0u) counts[count_index(plan, ly, bkt, tile)] = nrun[k];
                 }
             }
         } else {
@@ -216,10 +238,10 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 const size_t reg = region_index(plan, ly, bkt, tile);
                 Rec *__restrict__ dst = regions + reg * CAP;
                 for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
-                if (lane == 0u) counts[reg] = n;
+                if (lane == 0u) counts[count_index(plan, ly, bkt, tile)] = n;
             }
         }
-        __syncthreads();                                             // staging and this counter set are free again
+        lds_barrier();                                               // staging and this counter set are free again
     }
 }
 
@@ -244,7 +266,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = T_ >> 6;
-    const size_t reg0 = region_index(plan, ly, bucket, 0);
+    const size_t cnt0 = count_index(plan, ly, bucket, 0);
     auto add = [&](const Rec &r) {
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
@@ -260,7 +282,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const uint32_t per_wave = (((split_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
     const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
-        const uint32_t mine = t0 + lane < t_end ? counts[reg0 + t0 + lane] : 0u;
+        const uint32_t mine = t0 + lane < t_end ? counts[cnt0 + t0 + lane] : 0u;
         const uint32_t n_here = min(64u, t_end - t0);
         for (uint32_t j = 0; j < n_here; j += kGroup) {
             uint32_t n[kGroup], n_max = 0u;
@@ -270,7 +292,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                 const uint32_t tj = min(j + u, n_here - 1u);
                 n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
                 n_max = max(n_max, n[u]);
-                ra[u] = (regions + (reg0 + t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
+                ra[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
             }
             if (__builtin_amdgcn_readfirstlane(n_max) <= 64u + kTail) {
                 // the usual case: no run is longer than 64 + kTail records.  The tails (records 64..) of 64 / kTail regions
@@ -283,7 +305,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                     const uint32_t u = q * kPer + lane / kTail, slot = 64u + (lane % kTail);
                     const uint32_t tj = min(j + u, n_here - 1u);
                     nt[q] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
-                    rt[q] = (regions + (reg0 + t0 + tj) * CAP)[slot < nt[q] ? slot : 0u];
+                    rt[q] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[slot < nt[q] ? slot : 0u];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kGroup; ++u)
@@ -296,7 +318,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 #pragma unroll                                                              // per lane cover a whole region
                 for (uint32_t u = 0; u < kGroup; ++u) {
                     const uint32_t tj = min(j + u, n_here - 1u);
-                    rb[u] = (regions + (reg0 + t0 + tj) * CAP)[lane + 64u < n[u] ? lane + 64u : 0u];
+                    rb[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane + 64u < n[u] ? lane + 64u : 0u];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kGroup; ++u) {
