@@ -121,6 +121,39 @@ __device__ __forceinline__ float corner(uint32_t c, const float (&frac)[D], cons
     return w;
 }
 
+// All 2^D corners of a cell at once: weights in the reference's product order and rows from shared per-dimension terms.
+// (p+1)*k == p*k + k in uint32 arithmetic, so each dimension costs one multiply (a quarter-rate instruction on CDNA)
+// instead of one per corner; the rows are bit-identical to grid_row() on the corner coordinates.
+template <uint32_t MODE, uint32_t D>
+__device__ __forceinline__ void cell_corners(const LevelMeta &m, const float (&frac)[D], const uint32_t (&pg)[D],
+                                             float (&w)[1u << D], uint32_t (&row)[1u << D]) {
+    uint32_t term[D][2];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        uint32_t k;
+        if constexpr (MODE >= kHashMask) k = d == 0 ? 1u : d == 1 ? kPrime1 : kPrime2;
+        else k = d == 0 ? 1u : d == 1 ? m.stride1 : m.stride2;
+        term[d][0] = d == 0 ? pg[0] : pg[d] * k;
+        term[d][1] = term[d][0] + k;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < (1u << D); ++c) {
+        float wc = 1.0f;
+        uint32_t idx = 0u;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) {
+            const uint32_t bit = (c >> d) & 1u;
+            wc *= bit ? frac[d] : 1.0f - frac[d];
+            if constexpr (MODE >= kHashMask) idx ^= term[d][bit];
+            else idx += term[d][bit];
+        }
+        if constexpr (MODE == kDenseMask || MODE == kHashMask) idx &= (m.size - 1u);
+        else if constexpr (MODE != kDenseNoMod) idx %= m.size;
+        w[c] = wc;
+        row[c] = idx;
+    }
+}
+
 // ---- storage types ---------------------------------------------------------------------------
 struct F32 { using store_t = float; };
 struct F16 { using store_t = _Float16; };

@@ -512,12 +512,10 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
             uint32_t pg[3];
             src.get(b, x);
             locate<3>(x, m.scale, frac, pg);
+            uint32_t row[8];
+            cell_corners<MODE, 3>(m, frac, pg, w[k], row);
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) {
-                uint32_t pl[3];
-                w[k][c] = corner<3>(c, frac, pg, pl);
-                load_vec<TT, C>(grid + (size_t)grid_row<MODE, 3>(m, pl) * C, v[k][c]);
-            }
+            for (uint32_t c = 0; c < 8; ++c) load_vec<TT, C>(grid + (size_t)row[c] * C, v[k][c]);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kPts; ++k) {

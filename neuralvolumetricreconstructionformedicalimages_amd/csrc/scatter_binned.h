@@ -149,14 +149,12 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         }
         dispatch_mode(m.mode, [&](auto mode_tag) {
             constexpr uint32_t MODE = decltype(mode_tag)::value;
+            float w[8];
+            cell_corners<MODE, 3>(m, frac, pg, w, row);
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) {
-                uint32_t pl[3];
-                const float w = corner<3>(c, frac, pg, pl);
-                row[c] = grid_row<MODE, 3>(m, pl);
+            for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w * g[ch];
-            }
+                for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w[c] * g[ch];
         });
         // Cells wider than the sample spacing (wave-uniform decision): consecutive samples of a ray that fall into the
         // same cell hit the same 8 rows.  Merge each run of equal cells inside the wave (segmented inclusive scan);
