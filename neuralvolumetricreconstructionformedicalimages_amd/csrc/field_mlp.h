@@ -227,13 +227,12 @@ __device__ __forceinline__ f32x16 splat_slots(const float (&x)[16]) {
     return v;
 }
 __device__ __forceinline__ void leaky_inplace(f32x16 &z, float (&out)[16]) {
+    // slope < 1: max(z, 0.01 z) == LeakyReLU(z): v_mul + (canonicalise +) v_max.  Do NOT replace the fmaxf by an inline-asm
+    // v_max_f32 to drop the canonicalise: the hazard recogniser does not look into inline asm, and in some instantiations
+    // the read came too soon after the MFMA / v_accvgpr_read that produced z -- values off by ~5e-3, caught by the
+    // fp32 parity tests of the C = 4 / C = 8 shapes.
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {        // slope < 1: max(z, 0.01 z) == LeakyReLU(z).  The bare instruction: fmaxf() makes
-        const float zt = z[t], m = kLeaky * zt;   // the compiler canonicalise z first (a third VALU op per element)
-        float r;
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(zt), "v"(m));
-        out[t] = r;
-    }
+    for (int t = 0; t < 16; ++t) out[t] = fmaxf(z[t], kLeaky * z[t]);
 }
 
 // final activation and its derivative expressed through the OUTPUT y (network.py:23-32)

@@ -61,8 +61,12 @@ __device__ __forceinline__ LevelMeta make_level_meta(const int32_t *__restrict__
     m.stride2 = D > 2 ? strides[2] : 0u;
     const bool hashed = stride > m.size;
     const bool pow2 = (m.size & (m.size - 1u)) == 0u;
+    // Levels with 2^l * H >= 2^31 (only reachable with L > 27 at H = 16) overflow the uint32 resolution -- the float -> uint32
+    // conversions saturate on this hardware as they do in the reference's CUDA build, and `res` wraps to 0 -- so the
+    // no-modulo proof below does not hold for them: they always take a mask / modulo path (in bounds by construction).
+    const bool exact = m.scale < 2147483648.0f;
     if (hashed) m.mode = pow2 ? kHashMask : kHashMod;
-    else if (!wrapped && max_index < (uint64_t)m.size) m.mode = kDenseNoMod;
+    else if (exact && !wrapped && max_index < (uint64_t)m.size) m.mode = kDenseNoMod;
     else m.mode = pow2 ? kDenseMask : kDenseMod;
     return m;
 }

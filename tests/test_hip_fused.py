@@ -56,17 +56,17 @@ def test_unfused_module_path_matches_reference_golden(golden):
             np.testing.assert_allclose(lyr.weight.grad.cpu().numpy(), gw, rtol=0, atol=3e-5 * max(np.abs(gw).max(), 1e-12))
 
 
-def _naf_pair(seed=0, log2T=14, scale=0.5, last_activation="sigmoid"):
+def _naf_pair(seed=0, log2T=14, scale=0.5, last_activation="sigmoid", L=16, C=2, H=16):
     """Canonical NAF network (L=16,C=2,H=16 -> 32 features) on GPU + the oracle twin on CPU with equal weights."""
     _abi, encoder, fused, network = _mods()
     from oracle.hashgrid_ref import HashEncoderRef
     from oracle.network_ref import DensityNetworkRef
     torch.manual_seed(seed)
-    enc = encoder.HashEncoder(3, 16, 2, 16, log2T)
+    enc = encoder.HashEncoder(3, L, C, H, log2T)
     enc.embeddings.data.uniform_(-scale, scale)
     net = network.DensityNetwork(enc, bound=0.3, num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
                                  last_activation=last_activation)
-    ref_enc = HashEncoderRef(3, 16, 2, 16, log2T)
+    ref_enc = HashEncoderRef(3, L, C, H, log2T)
     ref_enc.embeddings.data.copy_(enc.embeddings.data)
     ref = DensityNetworkRef(ref_enc, bound=0.3, num_layers=4, hidden_dim=32, skips=(2,), out_dim=1,
                             last_activation=last_activation)
@@ -121,6 +121,73 @@ def test_fused_backward_fp32_vs_oracle(act):
         assert _rel_l2(a.bias.grad.cpu().numpy(), gb) < 2e-4, act
     ge = ref.encoder.embeddings.grad.numpy()
     assert _rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ge) < 2e-4
+
+
+@pytest.mark.parametrize("L,C", [(8, 4), (4, 8)])
+@pytest.mark.parametrize("scatter_mode", [1, 2])
+def test_fused_other_level_shapes_fp32_vs_oracle(L, C, scatter_mode):
+    """The fused kernels are templated on the channels per level; every L x C = 32 split runs the same MLP.  Forward
+    and all gradients against the oracle, with the atomic (1) and the binned (2) table-gradient scatter.
+    (C = 1 needs L = 32, whose top levels exceed fp32 coordinate resolution -- the torch oracle's unfused x*scale+0.5
+    then picks other cells than the fma of the kernels and of the C oracle; that shape is covered by the
+    binned-vs-atomic and the in-bounds tests below.)"""
+    from oracle import render_ref as R
+    _abi, encoder, fused, network = _mods()
+    net, ref = _naf_pair(seed=11, log2T=12, L=L, C=C)
+    assert net.fused_supported()
+    S, n = 64, 33
+    rays = _rays(n, seed=31)
+    t_rand = torch.rand(n, S, generator=torch.Generator().manual_seed(8))
+    target = torch.rand(n, generator=torch.Generator().manual_seed(9)) * 0.3
+    acc_ref = R.render(rays, ref, None, S, 0, True, 1 << 20, 0.0, t_rand=t_rand)["acc"]
+    ((acc_ref - target) ** 2).mean().backward()
+    try:
+        _abi.check(_abi.lib().naf_set_scatter_mode(scatter_mode))
+        acc = fused.fused_render(rays.cuda(), net, S, True, t_rand=t_rand.cuda())
+        ((acc - target.cuda()) ** 2).mean().backward()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    assert _rel_l2(acc.detach().cpu().numpy(), acc_ref.detach().numpy()) < 1e-4
+    for a, b in zip(net.layers, ref.layers):
+        assert _rel_l2(a.weight.grad.cpu().numpy(), b.weight.grad.numpy()) < 2e-4
+    assert _rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ref.encoder.embeddings.grad.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("L,C", [(32, 1), (8, 4), (4, 8)])
+def test_fused_other_level_shapes_bf16_binned_equals_atomic(L, C):
+    _abi, encoder, fused, network = _mods()
+    net, _ = _naf_pair(seed=12, log2T=15, scale=0.1, L=L, C=C, H=1 if L == 32 else 16)
+    n, S = 1024, 96
+    rays = _rays(n, seed=37).cuda()
+    target = torch.rand(n, device="cuda") * 0.3
+    grads = {}
+    try:
+        for mode in (1, 2):
+            _abi.check(_abi.lib().naf_set_scatter_mode(mode))
+            net.zero_grad()
+            acc = fused.fused_render(rays, net, S, True, seed=5, mlp_precision=_abi.BF16)
+            ((acc - target) ** 2).mean().backward()
+            grads[mode] = net.encoder.embeddings.grad.clone()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    a, b = grads[1].double(), grads[2].double()
+    assert float((a - b).norm() / a.norm()) < 3e-3
+
+
+def test_levels_beyond_uint32_resolution_stay_in_bounds():
+    """L=32 at H=16 asks for resolutions up to 2^35: the float -> uint32 conversions saturate (as in the reference's
+    CUDA build) and every such level must still index inside its table (mask / modulo path), forward and backward."""
+    _abi, encoder, fused, network = _mods()
+    torch.manual_seed(0)
+    enc = encoder.HashEncoder(3, 32, 1, 16, 12).cuda()
+    x = (torch.rand(4096, 3, device="cuda") - 0.5) * 0.59
+    x.requires_grad_(False)
+    y = enc(x, 0.3)
+    assert y.shape == (4096, 32) and bool(torch.isfinite(y).all())
+    assert float(y[:, 28:].abs().max()) <= 1e-4 + 1e-7              # values come from inside the U(-1e-4, 1e-4) table
+    y.sum().backward()
+    g = enc.embeddings.grad
+    assert bool(torch.isfinite(g).all()) and abs(float(g.sum()) - 4096 * 32) < 1.0     # every corner weight landed in the table
 
 
 def test_render_train_entry_matches_autograd_path():
