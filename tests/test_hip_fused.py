@@ -348,6 +348,48 @@ def test_binned_scatter_large_batch_split_reducer():
     assert float((a - b).abs().max() / a.abs().max()) < 3e-2
 
 
+def test_binned_scatter_ragged_tail_tile_bf16():
+    """1850 points = 3.6 bin tiles of 512: the threads past the end of the batch must contribute nothing."""
+    _abi, encoder, fused, network = _mods()
+    net, _ = _naf_pair(seed=13, log2T=16, scale=0.1)
+    n, S = 37, 50
+    rays = _rays(n, seed=41).cuda()
+    t_rand = torch.rand(n, S, device="cuda")
+    target = torch.rand(n, device="cuda") * 0.3
+    grads = {}
+    try:
+        for mode in (1, 2):
+            _abi.check(_abi.lib().naf_set_scatter_mode(mode))
+            net.zero_grad()
+            acc = fused.fused_render(rays, net, S, True, t_rand=t_rand, mlp_precision=_abi.BF16)
+            ((acc - target) ** 2).mean().backward()
+            grads[mode] = net.encoder.embeddings.grad.clone()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    a, b = grads[1].double(), grads[2].double()
+    assert float((a - b).norm() / a.norm()) < 3e-3
+    assert float((a - b).abs().max() / a.abs().max()) < 3e-2
+
+
+def test_more_samples_than_the_lds_depth_buffer():
+    """S = 1100 > 1024: the MLP kernels fall back from the per-ray LDS depth buffer to re-evaluating the depths."""
+    from oracle import render_ref as R
+    _abi, encoder, fused, network = _mods()
+    net, ref = _naf_pair(seed=14)
+    S, n = 1100, 5
+    rays = _rays(n, seed=43)
+    t_rand = torch.rand(n, S, generator=torch.Generator().manual_seed(2))
+    target = torch.rand(n, generator=torch.Generator().manual_seed(3)) * 0.3
+    acc_ref = R.render(rays, ref, None, S, 0, True, 1 << 20, 0.0, t_rand=t_rand)["acc"]
+    ((acc_ref - target) ** 2).mean().backward()
+    acc = fused.fused_render(rays.cuda(), net, S, True, t_rand=t_rand.cuda())
+    ((acc - target.cuda()) ** 2).mean().backward()
+    assert _rel_l2(acc.detach().cpu().numpy(), acc_ref.detach().numpy()) < 1e-4
+    assert _rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ref.encoder.embeddings.grad.numpy()) < 2e-4
+    for a, b in zip(net.layers, ref.layers):
+        assert _rel_l2(a.weight.grad.cpu().numpy(), b.weight.grad.numpy()) < 2e-4
+
+
 def test_foot_config_t22_fp16_table_and_long_rays():
     """foot_50-like shapes (BASELINE.json configs[4]): T=2^22 (wrapped-dense fine levels, 512 scatter buckets), fp16
     table, S=320 -- forward vs the oracle, binned vs atomic gradient."""
