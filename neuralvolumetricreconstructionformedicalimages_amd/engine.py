@@ -50,9 +50,17 @@ class NAFEngine:
         assert off == _abi.MLP_PARAMS
         self.table_dtype = table_dtype
         self.emb_lp = None if table_dtype == torch.float32 else self.emb.to(table_dtype)
-        self.emb_m, self.emb_v, self.emb_g = (torch.zeros_like(self.emb) for _ in range(3))
-        self.mlp_m, self.mlp_v, self.mlp_g = (torch.zeros_like(self.mlp) for _ in range(3))
-        self.loss = torch.zeros(1, device=dev)
+        self.emb_m, self.emb_v = (torch.zeros_like(self.emb) for _ in range(2))
+        self.mlp_m, self.mlp_v = (torch.zeros_like(self.mlp) for _ in range(2))
+        # table gradient | MLP gradient | loss in ONE flat buffer (sections 256-byte aligned): a data-parallel step is a
+        # single all-reduce
+        n_emb, n_mlp = self.emb.numel(), self.mlp.numel()
+        o_mlp = (n_emb + 63) // 64 * 64
+        o_loss = o_mlp + (n_mlp + 63) // 64 * 64
+        self.grad_flat = torch.zeros(o_loss + 64, device=dev)
+        self.emb_g = self.grad_flat[:n_emb].view(self.emb.shape)
+        self.mlp_g = self.grad_flat[o_mlp:o_mlp + n_mlp]
+        self.loss = self.grad_flat[o_loss:o_loss + 1]
         self.acc = None
         self.offsets = enc.offsets.to(dev)
         enc.offsets = self.offsets
@@ -153,9 +161,7 @@ class NAFEngine:
         if self.process_group is None:
             return
         import torch.distributed as dist
-        dist.all_reduce(self.emb_g, group=self.process_group)
-        dist.all_reduce(self.mlp_g, group=self.process_group)
-        dist.all_reduce(self.loss, group=self.process_group)
+        dist.all_reduce(self.grad_flat, group=self.process_group)       # table + MLP gradients + loss (sum over ranks)
 
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
