@@ -24,8 +24,8 @@
 // [bucket][tile] order at a 768-byte stride, only ~3 TB/s.  Waves never wait for these stores: the barriers inside the
 // level loop order LDS traffic only (lds_barrier), and the one global load of the loop is consumed before the stores.
 //
-// Bucket = LOW bits of the row, so dense coarse levels (whose rows are spatially ordered and heavily skewed toward the
-// volume centre) spread as evenly as the hashed ones.
+// Bucket = LOW bits of the row (rotated, see bucket_of), so dense coarse levels (whose rows are spatially ordered and
+// heavily skewed toward the volume centre) spread as evenly as the hashed ones.
 #pragma once
 
 #include "naf_device.h"
@@ -87,6 +87,20 @@ __device__ __forceinline__ long long to_fixed(float v, double scale) {
     return __double_as_longlong(d) - 0x4338000000000000ll;
 }
 
+// Row <-> (bucket, local row).  local = row >> log2 NB; the bucket is the low log2 NB bits of the row ROTATED by a function
+// of the local row, (row + local + (local >> 10)) & (NB-1): for a fixed local row the NB candidates still map one-to-one to
+// the buckets, so (bucket, local) identifies the row, but neighbouring corners no longer collide.  On dense and
+// uint32-wrapped dense levels row = x + s1 y + s2 z with s1 = s2 = 1 (mod 64): with the plain low bits the eight corners
+// of a cell fall into buckets b + {0,1,1,2,1,2,2,3}, and the triple hits overflow the staging runs (0.5 ms per step of
+// fallback atomics); rotated they fall into b + {0,1,2,3,3,4,5,6}.
+__device__ __forceinline__ uint32_t bucket_twist(uint32_t local) { return local + (local >> 10); }
+__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb) {
+    return (row + bucket_twist(row >> log2_nb)) & ((1u << log2_nb) - 1u);
+}
+__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb) {
+    return (local << log2_nb) | ((bucket - bucket_twist(local)) & ((1u << log2_nb) - 1u));
+}
+
 // run lengths: [level][bucket][tile] (one coalesced load per 64 tiles in pass 2); records: [level][tile][bucket][slot_cap]
 __device__ __forceinline__ size_t count_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
     return (((size_t)ly << plan.log2_nb) + bucket) * plan.n_tiles + tile;
@@ -101,7 +115,7 @@ __device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly,
 // is being computed.  With 8-byte records the launch uses NT = 512: LDS allows two or three workgroups per CU either
 // way, and 16+ resident waves hide the input loads and the staging round trips far better than 8 (5.6 -> 4.7 ms/step).
 template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t LV>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NT == 512u ? 6 : 1)      // 512 threads: three workgroups (24 waves) per CU -> <= 80 VGPRs
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
@@ -128,6 +142,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     if (blockIdx.y * LV < n_levels) raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + b) * C, graw);
     raw_unpack<FT, C>(graw, g);
     __syncthreads();
+    uint32_t n_overflow = 0;
 
     for (uint32_t it = 0; it < LV; ++it) {
         const uint32_t ly = blockIdx.y * LV + it;
@@ -180,19 +195,22 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         }
         // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
         if (emit) {
-            uint32_t pos[8];
+            uint32_t pos[8], bkt[8];
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) pos[c] = atomicAdd(&cnt[row[c] & mask], 1u);
+            for (uint32_t c = 0; c < 8; ++c) {
+                bkt[c] = bucket_of(row[c], plan.log2_nb);
+                pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
+            }
 #pragma unroll
             for (uint32_t c = 0; c < 8; ++c) {
                 if (pos[c] < CAP) {
                     Rec r;
                     r.set(row[c] >> plan.log2_nb, val[c]);
-                    staging[(row[c] & mask) * CAP + pos[c]] = r;
+                    staging[bkt[c] * CAP + pos[c]] = r;
                 } else {
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[c] * C + ch, val[c][ch]);
-                    atomicAdd(overflow, 1u);
+                    ++n_overflow;
                 }
             }
         }
@@ -241,6 +259,11 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         }
         lds_barrier();                                               // staging and this counter set are free again
     }
+    if (__ballot(n_overflow != 0u)) {                                // statistics only: one atomic per wave that overflowed
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_overflow += __shfl_xor(n_overflow, off, 64);
+        if (lane == 0u) atomicAdd(overflow, n_overflow);
+    }
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------------------
@@ -259,7 +282,9 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const uint32_t NB = 1u << plan.log2_nb, T_ = blockDim.x, CAP = plan.slot_cap;
     const uint32_t bucket = blockIdx.x, ly = blockIdx.y, level = level_base + ly;
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
-    const uint32_t rows_local = bucket < T ? (T - bucket + NB - 1u) >> plan.log2_nb : 0u;    // rows with row % NB == bucket
+    // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
+    const uint32_t full_groups = T >> plan.log2_nb;
+    const uint32_t rows_local = full_groups + (row_of(bucket, full_groups, plan.log2_nb) < T ? 1u : 0u);
     for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
@@ -330,7 +355,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     float *__restrict__ gg = grad_table + (size_t)off * C;
     for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
         const uint32_t local = i / C, ch = i - local * C;
-        const size_t dst = ((size_t)local << plan.log2_nb) + bucket;
+        const size_t dst = row_of(bucket, local, plan.log2_nb);
         const float sum = (float)ldexp((double)(long long)acc[i], -shift);
         if (gridDim.z == 1u) gg[dst * C + ch] += sum;                                  // sole owner of these rows
         else atomicAdd(gg + dst * C + ch, sum);                                        // one add per row and split
