@@ -368,21 +368,34 @@ loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target
     }
 }
 
-// ---- 5: slabs -> grad_mlp (+=), summed in workgroup order (deterministic) -----------------------------------
+// ---- 5: slabs -> grad_mlp (+=), summed in a fixed order (deterministic) ---------------------------------------
+// 256 threads = 32 parameters x 8 slab groups: group g adds slabs g, g+8, ... (four independent chains), the eight
+// partial sums are combined through LDS in group order.
+constexpr uint32_t kReduceParams = 32, kReduceGroups = 8;
 __global__ void __launch_bounds__(256)
 mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kMlpParams) return;
+    __shared__ float part[kReduceGroups][kReduceParams];
+    const uint32_t j = threadIdx.x % kReduceParams, g = threadIdx.x / kReduceParams;
+    const uint32_t i = blockIdx.x * kReduceParams + j;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    uint32_t k = 0;
-    for (; k + 4 <= n_slabs; k += 4) {
-        s0 += slabs[(size_t)(k + 0) * kSlabStride + i];
-        s1 += slabs[(size_t)(k + 1) * kSlabStride + i];
-        s2 += slabs[(size_t)(k + 2) * kSlabStride + i];
-        s3 += slabs[(size_t)(k + 3) * kSlabStride + i];
+    if (i < kMlpParams) {
+        uint32_t k = g;
+        for (; k + 3u * kReduceGroups < n_slabs; k += 4u * kReduceGroups) {
+            s0 += slabs[(size_t)(k + 0u * kReduceGroups) * kSlabStride + i];
+            s1 += slabs[(size_t)(k + 1u * kReduceGroups) * kSlabStride + i];
+            s2 += slabs[(size_t)(k + 2u * kReduceGroups) * kSlabStride + i];
+            s3 += slabs[(size_t)(k + 3u * kReduceGroups) * kSlabStride + i];
+        }
+        for (; k < n_slabs; k += kReduceGroups) s0 += slabs[(size_t)k * kSlabStride + i];
     }
-    for (; k < n_slabs; ++k) s0 += slabs[(size_t)k * kSlabStride + i];
-    grad_mlp[i] += (s0 + s1) + (s2 + s3);
+    part[g][j] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < kMlpParams) {
+        float total = 0.0f;
+#pragma unroll
+        for (uint32_t q = 0; q < kReduceGroups; ++q) total += part[q][j];
+        grad_mlp[i] += total;
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -589,7 +602,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
                        (typename P::feat_t::store_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
-    { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + 255) / 256), dim3(256), 0, s, slabs, grid, grad_mlp); }
+    { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + kReduceParams - 1) / kReduceParams), dim3(256), 0, s, slabs, grid, grad_mlp); }
     return check_launch("mlp_grad_reduce_kernel");
 }
 
