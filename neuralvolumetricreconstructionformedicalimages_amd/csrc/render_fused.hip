@@ -417,6 +417,7 @@ struct Workspace {
     uint32_t *counts;            //                 records per region
     uint32_t *overflow;          //                 contributions that fell back to atomics (diagnostic counter)
     uint32_t *gmax;              //                 bit pattern of max |feature gradient| of the step (fixed-point scale)
+    float *sums;                 //                 finished row sums [level][bucket][local][C] between pass 2 and pass 3
     BinPlan plan;
     bool binned;
     size_t bytes;
@@ -472,6 +473,7 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
     w.counts = nullptr;
     w.overflow = nullptr;
     w.gmax = nullptr;
+    w.sums = nullptr;
     if (w.binned) {
         const size_t n_streams = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * w.plan.n_tiles;     // regions
         const size_t stream_bytes = (n_streams * w.plan.slot_cap * record_bytes(cfg) + 255) & ~(size_t)255;
@@ -480,6 +482,8 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
         w.overflow = w.counts + n_streams;
         w.gmax = w.overflow + 1;
         w.bytes += stream_bytes + (((n_streams + 2) * 4 + 255) & ~(size_t)255);
+        w.sums = (float *)((unsigned char *)base + w.bytes);
+        w.bytes += ((((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * sums_rows(w.plan) * cfg->C * 4) + 255) & ~(size_t)255;
     }
     return w;
 }
@@ -639,7 +643,10 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
           // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles
           const uint32_t n_split = std::max(1u, std::min(16u, 1024u / (NB * nl)));
           hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                             grad_table, w.gmax, l0, plan); }
+                             grad_table, w.sums, w.gmax, l0, plan);
+          if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
+              hipLaunchKernelGGL((scatter_apply_kernel<C>), dim3((plan.max_local_rows + 63u) / 64u, nl, NB / 64u), dim3(256), 0, s,
+                                 w.sums, offsets, grad_table, l0, plan); }
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }
     return NAF_OK;

@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint
     return (local << log2_nb) | ((bucket - bucket_twist(local)) & ((1u << log2_nb) - 1u));
 }
 
+// rows per bucket in the sums buffer of pass 2 (a multiple of 64: pass 3 works on 64-row blocks)
+__host__ __device__ __forceinline__ size_t sums_rows(const BinPlan &plan) { return ((size_t)plan.max_local_rows + 63u) & ~(size_t)63u; }
+
 // run lengths: [level][bucket][tile] (one coalesced load per 64 tiles in pass 2); records: [level][tile][bucket][slot_cap]
 __device__ __forceinline__ size_t count_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
     return (((size_t)ly << plan.log2_nb) + bucket) * plan.n_tiles + tile;
@@ -274,7 +277,8 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 template <uint32_t C, typename Rec>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
-                      float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, BinPlan plan) {
+                      float *__restrict__ grad_table, float *__restrict__ sums, const uint32_t *__restrict__ gmax_bits,
+                      uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int shift = fixed_shift(*gmax_bits);
     const double scale = ldexp(1.0, shift);
@@ -352,13 +356,49 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         }
     }
     __syncthreads();
+    if (gridDim.z == 1u) {
+        // sole owner of these rows, but they are NB rows apart in the table: write the finished sums as one contiguous block
+        // [level][bucket][local][C]; scatter_apply_kernel adds them to the table with coalesced accesses on both sides
+        float *__restrict__ dst = sums + (((size_t)ly << plan.log2_nb) + bucket) * sums_rows(plan) * C;
+        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) dst[i] = (float)ldexp((double)(long long)acc[i], -shift);
+    } else {
+        float *__restrict__ gg = grad_table + (size_t)off * C;
+        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
+            const uint32_t local = i / C, ch = i - local * C;
+            atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb) * C + ch,
+                      (float)ldexp((double)(long long)acc[i], -shift));             // one add per row and split
+        }
+    }
+}
+
+// ---- pass 3 ---------------------------------------------------------------------------------------------------
+// grad_table[row] += sums[level][bucket][local] for row = row_of(bucket, local).  One workgroup = 64 local rows x 64
+// buckets: the block is read bucket-major (64 local rows x C floats contiguous per bucket), turned in LDS and added to
+// the table row-major (the 64 buckets of one local row are 64 consecutive rows, in rotated order).  Doing this
+// read-modify-write straight from the reducer touches every 64-byte sector of the table for 8 useful bytes.
+template <uint32_t C>
+__global__ void __launch_bounds__(256)
+scatter_apply_kernel(const float *__restrict__ sums, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
+                     uint32_t level_base, BinPlan plan) {
+    __shared__ float tile[64][64 * C + 1];                      // [bucket in group][local in block][C], odd pitch
+    const uint32_t ly = blockIdx.y, level = level_base + ly, local0 = blockIdx.x * 64u, bucket0 = blockIdx.z * 64u;
+    const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
+    if (((size_t)local0 << plan.log2_nb) >= T) return;          // block past the end of this level (uniform)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t rows = sums_rows(plan);
+    for (uint32_t b = wave; b < 64u; b += 4u) {
+        const float *src_b = sums + ((((size_t)ly << plan.log2_nb) + bucket0 + b) * rows + local0) * C;
+#pragma unroll
+        for (uint32_t k = 0; k < C; ++k) tile[b][lane + 64u * k] = src_b[lane + 64u * k];      // element e = local * C + ch
+    }
+    __syncthreads();
     float *__restrict__ gg = grad_table + (size_t)off * C;
-    for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
-        const uint32_t local = i / C, ch = i - local * C;
-        const size_t dst = row_of(bucket, local, plan.log2_nb);
-        const float sum = (float)ldexp((double)(long long)acc[i], -shift);
-        if (gridDim.z == 1u) gg[dst * C + ch] += sum;                                  // sole owner of these rows
-        else atomicAdd(gg + dst * C + ch, sum);                                        // one add per row and split
+    for (uint32_t j = wave; j < 64u; j += 4u) {
+        const uint32_t row = row_of(bucket0 + lane, local0 + j, plan.log2_nb);
+        if (row < T) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ++ch) gg[(size_t)row * C + ch] += tile[lane][j * C + ch];
+        }
     }
 }
 
