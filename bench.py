@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16", help="table storage / MLP operand type")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
+                    help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_set_scatter_mode)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
@@ -120,6 +122,8 @@ def main():
     from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
     from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
     from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
+
+    _abi.check(_abi.lib().naf_set_scatter_mode({"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode]), "set_scatter_mode")
 
     # ---- chest_50 scan: geometry, poses, phantom ----------------------------------------------------------------
     geo = ConeGeometry(phantom.scan_geometry(CHEST["n_voxel"], "cone"))

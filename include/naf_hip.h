@@ -128,7 +128,7 @@ typedef struct naf_render_cfg {
 } naf_render_cfg;
 
 /* How naf_render_backward / naf_render_train scatter the table gradient: 0 = auto (binned two-pass scatter from
- * 2^17 points per call, plain fp32 atomics below), 1 = always atomics (the reference's scheme, hashencoder.cu:257-269),
+ * 2^13 points per call, plain fp32 atomics below), 1 = always atomics (the reference's scheme, hashencoder.cu:257-269),
  * 2 = always binned.  Process-wide; call before naf_render_workspace_bytes (the workspace size depends on it). */
 int naf_set_scatter_mode(int mode);
 

@@ -423,7 +423,7 @@ struct Workspace {
     size_t bytes;
 };
 
-constexpr uint64_t kBinMinPoints = 1u << 17;             // below this the plain atomic kernel is launch-bound anyway
+constexpr uint64_t kBinMinPoints = 1u << 13;             // measured: 128 rays x 192 samples 0.62 ms (atomics) vs 0.36 ms (binned) per step
 constexpr size_t kBinBudgetBytes = (size_t)24 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
                                                          // step fit, so the reducer gets 1024 workgroups to balance over 256 CUs
 
