@@ -14,9 +14,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 echo fetch done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_write.json 2> $OUT/write.err
 echo write done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/mfma -o mfma -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_mfma.json 2> $OUT/mfma.err
+echo mfma done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_sqa.json 2> $OUT/sqa.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_sqb.json 2> $OUT/sqb.err
+echo sq done
 timeout -k 10 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo default done
-for r in 1024 4096 16384 65536 262144 1048576; do
+for r in 128 1024 4096 16384 65536 262144 1048576; do
   timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays $r --cpu-seconds 0 >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
 done
 echo sweep done

@@ -50,3 +50,51 @@ traffic = {
 }
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 print("profiles/pmc_traffic.json", {k: round(v / 1e9, 2) for k, v in traffic["bf16"].items()})
+
+
+# ---- SQ instruction mix and MFMA utilisation -------------------------------------------------------------------------
+import collections  # noqa: E402
+import csv  # noqa: E402
+import re  # noqa: E402
+
+
+def counters(*files):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        path = os.path.join(SRC, f)
+        if not os.path.exists(path):
+            continue
+        for r in csv.DictReader(open(path)):
+            name = re.sub(r"<.*", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("naf::", "")
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+sq = counters("sqa/sqa_counter_collection.csv", "sqb/sqb_counter_collection.csv")
+mf = counters("mfma/mfma_counter_collection.csv")
+kernels = ("encode_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "scatter_apply_kernel")
+out = ["# Counter evidence per kernel (MI355X, chest_50 bf16, 65 536 rays/step = 12.58 M points; tools/collect_profiles.sh)", "",
+       "## Dynamic instruction mix", "",
+       "`rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0`,",
+       "second pass `SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY`.", "",
+       "| kernel | waves | VALU / wave | SALU / wave | LDS / wave | VMEM rd / wave | VMEM wr / wave | VALU issue time (4 cyc x insts / 1024 SIMDs @ 2.4 GHz) | LDS bank-conflict cycles / CU |",
+       "|---|---|---|---|---|---|---|---|---|"]
+for k in kernels:
+    row = sq.get(k)
+    if not row or "SQ_WAVES" not in row:
+        continue
+    w = row["SQ_WAVES"]
+    out.append(f"| {k} | {w:.0f} | {row['SQ_INSTS_VALU'] / w:.0f} | {row['SQ_INSTS_SALU'] / w:.0f} | {row['SQ_INSTS_LDS'] / w:.0f} | "
+               f"{row['SQ_INSTS_VMEM_RD'] / w:.1f} | {row['SQ_INSTS_VMEM_WR'] / w:.1f} | {row['SQ_INSTS_VALU'] * 4 / 1024 / 2.4e6:.2f} ms | "
+               f"{row.get('SQ_LDS_BANK_CONFLICT', 0) / 256 / 1e6:.2f} M |")
+out += ["", "## MFMA utilisation of the MLP kernels", "",
+        "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0`", "",
+        "| kernel | SQ_INSTS_MFMA | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CU_CYCLES | MFMA busy / (4 SIMD x CU busy) |", "|---|---|---|---|---|"]
+for k in ("mlp_forward_kernel", "mlp_backward_kernel"):
+    row = mf.get(k)
+    if not row:
+        continue
+    out.append(f"| {k} | {row['SQ_INSTS_MFMA']:.0f} | {row['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} | {row['SQ_BUSY_CU_CYCLES']:.0f} | "
+               f"{100 * row['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * row['SQ_BUSY_CU_CYCLES']):.1f} % |")
+open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
