@@ -7,7 +7,7 @@
 // A level of the table gets ~50-200 contributions per row per step, but they are hash-scattered, so no locality trick
 // removes them -- they have to be ROUTED to an owner instead (a one-digit radix multisplit on the row index):
 //
-//   pass 1  bin      one workgroup = one tile of 512 points x up to four consecutive levels.  Per level every thread takes
+//   pass 1  bin      one workgroup = one tile of 512 points x LV consecutive levels (all 16, or 4 when tiles are scarce).  Per level every thread takes
 //                    an LDS slot for each of its 8 contributions in the bucket's staging run (bucket = row & (NB-1), one
 //                    returning LDS atomic per record) and writes the record (row >> log2 NB, w*g[0..C)) there; the runs are
 //                    then copied to fixed-size global REGIONS [level][tile][bucket][slot_cap] with 16-byte stores that
