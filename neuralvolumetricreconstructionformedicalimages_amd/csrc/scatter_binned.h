@@ -289,14 +289,17 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
     const uint32_t full_groups = T >> plan.log2_nb;
     const uint32_t rows_local = full_groups + (row_of(bucket, full_groups, plan.log2_nb) < T ? 1u : 0u);
-    for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) acc[i] = 0ull;
+    // accumulators are channel-major, acc[ch][local row]: the two 8-byte cells of a row would otherwise sit 8 bytes apart and
+    // one ds_add_u64 instruction (one channel of 64 rows) could reach only every other bank pair
+    const uint32_t pitch = plan.max_local_rows;
+    for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = T_ >> 6;
     const size_t cnt0 = count_index(plan, ly, bucket, 0);
     auto add = [&](const Rec &r) {
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[r.w[0] * C + ch], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
+        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[ch * pitch + r.w[0]], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
     };
     // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
     // kGroup at a time with straight-line code: 2*kGroup unconditional loads per lane are in flight before the first
@@ -360,13 +363,16 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         // sole owner of these rows, but they are NB rows apart in the table: write the finished sums as one contiguous block
         // [level][bucket][local][C]; scatter_apply_kernel adds them to the table with coalesced accesses on both sides
         float *__restrict__ dst = sums + (((size_t)ly << plan.log2_nb) + bucket) * sums_rows(plan) * C;
-        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) dst[i] = (float)ldexp((double)(long long)acc[i], -shift);
+        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
+            const uint32_t local = i / C, ch = i - local * C;
+            dst[i] = (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
+        }
     } else {
         float *__restrict__ gg = grad_table + (size_t)off * C;
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
             atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb) * C + ch,
-                      (float)ldexp((double)(long long)acc[i], -shift));             // one add per row and split
+                      (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));             // one add per row and split
         }
     }
 }
