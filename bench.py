@@ -207,7 +207,10 @@ def main():
 
         def roof(group):
             t = ms_per_step[group] * 1e-3
-            base = {"kernel": group, "per_step_ms": round(ms_per_step[group], 4), "points_per_step": points_per_launch}
+            members = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in kernels.items()
+                       if any(k.startswith(m) for m in groups[group])}
+            base = {"kernel": group, "per_step_ms": round(ms_per_step[group], 4), "points_per_step": points_per_launch,
+                    "member_kernels_avg_launch_ms": members}       # HIP-event average per launch; compare with the rocprofv3 CSV
             if group in ("hash_forward", "hash_backward"):
                 bytes_pp = algorithmic_bytes_per_point("encode_kernel" if group == "hash_forward" else "hash_backward_kernel", *sizes)
                 achieved = bytes_pp * points_per_launch / t / 1e9
