@@ -440,7 +440,8 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
     // pass-1 tile: one point per thread, 512 threads for 8-byte records; its records wait in LDS slots [bucket][slot_cap]
-    const uint32_t tile = record_bytes(cfg) <= 8 ? 512u : 256u;
+    // 1024-point tiles when a level needs >= 256 buckets (T = 2^21 and up): runs would otherwise shrink below a 128-byte line
+    const uint32_t tile = record_bytes(cfg) <= 8 ? (log2_nb >= 7 ? 1024u : 512u) : 256u;
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
@@ -610,11 +611,10 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     return check_launch("mlp_grad_reduce_kernel");
 }
 
-template <typename P, uint32_t C, typename Rec>
-static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                              const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+template <typename P, uint32_t C, typename Rec, uint32_t NT>
+static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                                 const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
     using FT = typename P::feat_t;
-    constexpr uint32_t NT = sizeof(Rec) <= 8 ? 512u : 256u;      // points per tile, must match make_bin_plan
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
     // position is evaluated once per point, and stores drain behind the next level: 3.85 -> 3.53 ms at 65 536 rays),
     // four when tiles are scarce (1 024-ray steps: 0.093 -> 0.071 ms)
@@ -661,6 +661,17 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }
     return NAF_OK;
+}
+
+template <typename P, uint32_t C, typename Rec>
+static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                              const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+    if constexpr (sizeof(Rec) <= 8) {                            // tile size chosen by make_bin_plan
+        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+    } else {
+        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+    }
 }
 
 template <typename P, uint32_t C>

@@ -118,7 +118,7 @@ __device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly,
 // is being computed.  With 8-byte records the launch uses NT = 512: LDS allows two or three workgroups per CU either
 // way, and 16+ resident waves hide the input loads and the staging round trips far better than 8 (5.6 -> 4.7 ms/step).
 template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t LV>
-__global__ void __launch_bounds__(NT, NT == 512u ? 6 : 1)      // 512 threads: three workgroups (24 waves) per CU -> <= 80 VGPRs
+__global__ void __launch_bounds__(NT, NT == 512u ? 6 : NT == 1024u ? 4 : 1)   // 512 threads: three workgroups (24 waves) per CU -> <= 80 VGPRs
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
