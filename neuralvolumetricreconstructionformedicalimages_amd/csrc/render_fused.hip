@@ -6,10 +6,12 @@
 // its sample position from the 32-byte ray record and the jitter (explicit t_rand or the counter-based generator).
 //
 // Kernels of one training step (B = n_rays * S points, feature tensors are [L, B, C]):
-//   1 hash_forward_kernel<SrcRays>   gathers  -> feat                 (hash_kernels.h)
+//   1 encode_kernel                  gathers  -> feat                 level-major, four points per lane
 //   2 mlp_forward_kernel             feat -> sigma -> acc[r]          one wave per ray, wave-reduced line integral
-//   3 mlp_backward_kernel            feat, acc, target -> dfeat, per-workgroup dW slabs, loss
-//   4 hash_backward_kernel<SrcRays>  dfeat -> grad table (fp32 atomics)
+//   - loss_grad_kernel               acc, target, weight -> d loss / d acc, loss
+//   3 mlp_backward_kernel            feat, d acc -> dfeat, per-workgroup dW slabs
+//   4 scatter_bin / scatter_reduce / scatter_apply (scatter_binned.h)   dfeat -> grad table, no global atomics;
+//     hash_backward_kernel<SrcRays> (hash_kernels.h, fp32 atomics like the reference) below 2^13 points per call
 //   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=)
 #include <algorithm>
 #include <cmath>

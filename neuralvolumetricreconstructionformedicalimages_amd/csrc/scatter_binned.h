@@ -302,10 +302,11 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[ch * pitch + r.w[0]], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
     };
     // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
-    // kGroup at a time with straight-line code: 2*kGroup unconditional loads per lane are in flight before the first
-    // LDS atomic (lanes past a run length read slot 0, a line that is fetched anyway -> no extra traffic).
+    // kGroup at a time with straight-line code: kGroup loads for records 0..63 plus kGroup * kTail / 64 loads for the tails
+    // are in flight per lane before the first LDS atomic (lanes past a run length read slot 0, a line that is fetched
+    // anyway -> no extra traffic).
     constexpr uint32_t kGroup = 8, kTail = 16;
-    // every wave streams ONE contiguous range of tiles (regions of consecutive tiles are adjacent in memory)
+    // every wave streams ONE contiguous range of tiles
     // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
     const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
     const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
