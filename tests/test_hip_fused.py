@@ -522,3 +522,40 @@ def test_fine_pass_and_sample_pdf_match_reference_golden(golden):
     acc, w = R.raw2outputs(torch.from_numpy(g["r2o/raw"]).cuda(), torch.from_numpy(g["r2o/z"]).cuda(), torch.from_numpy(g["r2o/d"]).cuda())
     np.testing.assert_allclose(acc.cpu().numpy(), g["r2o/acc"], rtol=2e-6)
     np.testing.assert_allclose(w.cpu().numpy(), g["r2o/weights"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_fused_randomised_shapes_fp32_vs_oracle(case):
+    """Seeded sweep over ray counts, sample counts, jitter on/off, table sizes, activations and both scatter paths:
+    forward and every gradient of the fused fp32 path against the oracle."""
+    from oracle import render_ref as R
+    _abi, encoder, fused, network = _mods()
+    rng = np.random.RandomState(1000 + case)
+    n = int(rng.choice([1, 3, 17, 64, 130]))
+    S = int(rng.choice([2, 7, 33, 64, 200, 321]))
+    perturb = bool(rng.randint(2))
+    log2T = int(rng.choice([8, 11, 14, 17]))
+    act = str(rng.choice(["sigmoid", "relu", "tanh", "none"]))
+    mode = int(rng.choice([1, 2]))
+    net, ref = _naf_pair(seed=20 + case, log2T=log2T, last_activation=act)
+    rays = _rays(n, seed=50 + case)
+    gen = torch.Generator().manual_seed(70 + case)
+    t_rand = torch.rand(n, S, generator=gen)
+    target = torch.rand(n, generator=gen) * 0.3
+    acc_ref = R.render(rays, ref, None, S, 0, perturb, 1 << 20, 0.0, t_rand=t_rand)["acc"]
+    ((acc_ref - target) ** 2).mean().backward()
+    try:
+        _abi.check(_abi.lib().naf_set_scatter_mode(mode))
+        acc = fused.fused_render(rays.cuda(), net, S, perturb, t_rand=t_rand.cuda())
+        ((acc - target.cuda()) ** 2).mean().backward()
+    finally:
+        _abi.check(_abi.lib().naf_set_scatter_mode(0))
+    tag = f"n={n} S={S} perturb={perturb} log2T={log2T} act={act} mode={mode}"
+    assert _rel_l2(acc.detach().cpu().numpy(), acc_ref.detach().numpy()) < 1e-4, tag
+    ge = ref.encoder.embeddings.grad.numpy()
+    assert _rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ge) < 3e-4, tag
+    for a, b in zip(net.layers, ref.layers):
+        gw = b.weight.grad.numpy()
+        if np.abs(gw).max() > 0:
+            assert _rel_l2(a.weight.grad.cpu().numpy(), gw) < 3e-4, tag
+
