@@ -125,7 +125,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                    BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t NW = NT / 64u;
-    const uint32_t NB = 1u << plan.log2_nb, mask = NB - 1u, CAP = plan.slot_cap;
+    const uint32_t NB = 1u << plan.log2_nb, CAP = plan.slot_cap;
     uint32_t *cnt2 = reinterpret_cast<uint32_t *>(smem);
     Rec *staging = reinterpret_cast<Rec *>(cnt2 + 2u * NB);
     const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -283,7 +283,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const int shift = fixed_shift(*gmax_bits);
     const double scale = ldexp(1.0, shift);
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
-    const uint32_t NB = 1u << plan.log2_nb, T_ = blockDim.x, CAP = plan.slot_cap;
+    const uint32_t T_ = blockDim.x, CAP = plan.slot_cap;
     const uint32_t bucket = blockIdx.x, ly = blockIdx.y, level = level_base + ly;
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
@@ -325,7 +325,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                 n_max = max(n_max, n[u]);
                 ra[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
             }
-            if (__builtin_amdgcn_readfirstlane(n_max) <= 64u + kTail) {
+            if ((uint32_t)__builtin_amdgcn_readfirstlane(n_max) <= 64u + kTail) {
                 // the usual case: no run is longer than 64 + kTail records.  The tails (records 64..) of 64 / kTail regions
                 // share one load and one pair of LDS atomics, kTail lanes per region, instead of a nearly empty wave each.
                 constexpr uint32_t kPer = 64u / kTail;                      // regions per tail instruction
