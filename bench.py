@@ -109,12 +109,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    # Rehearsal hooks for a one-GPU box (the real multi-GPU run uses neither): NAF_BENCH_BACKEND=gloo swaps RCCL for gloo,
+    # NAF_BENCH_SHARE_GPU=1 puts every rank on device 0.
+    backend = os.environ.get("NAF_BENCH_BACKEND", "nccl")
+    if os.environ.get("NAF_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from neuralvolumetricreconstructionformedicalimages_amd import _abi, phantom
@@ -187,10 +195,24 @@ def main():
     final_loss = float(loss.item())
     overflow = engine.scatter_overflow(n)
 
+    allreduce_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        try:        # informational: cost of the one collective of a step (table + MLP gradients + loss), outside the timed region
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            engine.grad_flat.zero_()
+            torch.distributed.all_reduce(engine.grad_flat)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                torch.distributed.all_reduce(engine.grad_flat)
+            e1.record()
+            torch.cuda.synchronize()
+            allreduce_ms = e0.elapsed_time(e1) / 5
+        except Exception as exc:                                       # never let the probe break the benchmark line
+            log(f"all-reduce probe skipped: {exc}")
 
     if rank == 0:
         rays_total = world * n * args.steps
@@ -239,6 +261,8 @@ def main():
                                    f"{n} rays/step/GPU (reference n_rays=1024), perturb=True",
                        "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "parallelism": f"dp{world}"},
             "final_loss": final_loss, "scatter_overflow_last_step": overflow,
+            "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
+            "allreduce_bytes": engine.grad_flat.numel() * 4,
             "roofline": roofline,
             "roofline_hash_forward": roof("hash_forward"),
             "roofline_all": {g: roof(g) for g in ms_per_step if g != "adam"},

@@ -79,3 +79,29 @@ def test_two_rank_training_equals_single_process():
     np.testing.assert_allclose(results[0][2], mlp, rtol=0, atol=2e-4)
     assert np.mean(np.abs(results[0][1] - emb) > 2e-3) < 1e-3
     np.testing.assert_allclose(results[0][3], loss, rtol=1e-3)
+
+
+def test_bench_two_rank_launch_rehearsal():
+    """`bench.py --gpus 2` under torch.distributed.run exactly as the driver launches it, except that the two ranks share
+    the one GPU of the test box and talk through gloo (NAF_BENCH_BACKEND / NAF_BENCH_SHARE_GPU rehearsal hooks): one JSON
+    line from rank 0 with the whole-job rate, the MAX-over-ranks time and the all-reduce probe."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, NAF_BENCH_BACKEND="gloo", NAF_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "2048"]
+    res = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 2048 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["allreduce_ms_per_step"] is not None and out["allreduce_bytes"] > 57_000_000
+    assert "cpu_baseline" not in out                               # rank 0 at N = 1 only
