@@ -118,7 +118,7 @@ __device__ __forceinline__ float sample_dist(const SrcRays &src, uint32_t r, uin
 // ---- 2: MLP forward + line integral ----------------------------------------------------------------------
 // kRays: one wave per ray, acc[r] = sum_s sigma*dist.   !kRays: plain point list, out[p] = sigma(p).
 template <typename P, uint32_t C, bool kRays>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                    float *__restrict__ out, uint32_t n_items, uint32_t B, int act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
