@@ -16,10 +16,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "naf_host.h"
 #include "hash_kernels.h"
 #include "field_mlp.h"
+#include "field_mlp16.h"
 #include "scatter_binned.h"
 
 namespace naf {
@@ -168,6 +170,61 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
             load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
             const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
             if (valid && h == 0) out[p] = last_act(act, z4);
+        }
+    }
+}
+
+// ---- 2b: the same on 16-point tiles (bf16 mode, C = 2; field_mlp16.h) -------------------------------------------
+template <bool kRays>
+__global__ void __launch_bounds__(256, 4)
+mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src, float *__restrict__ out,
+                     uint32_t n_items, uint32_t B, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Mlp16Shared::build(smem, mlp, 4);
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    Act16 a;
+    if constexpr (kRays) {
+        const uint32_t S = src.S, tiles = (S + 15u) / 16u;
+        const bool use_zbuf = S <= kMaxSamplesLds;
+        float *zbuf = reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u)) + (threadIdx.x >> 6) * kMaxSamplesLds;
+        Feat16Raw ahead;                                     // features of the next tile, in flight during this one
+        if (wave < n_items) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
+        for (uint32_t r = wave; r < n_items; r += n_waves) {
+            const float *ray = src.rays + (size_t)r * 8;
+            const float near = ray[6], far = ray[7];
+            const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+            if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
+            float part = 0.0f;
+            for (uint32_t k = 0; k < tiles; ++k) {
+                const uint32_t s = 16u * k + c;
+                const bool valid = s < S;
+                const Feat16Raw now = ahead;
+                {   // next tile of this ray, else first tile of this wave's next ray, else (nothing left) this tile again
+                    const bool more = k + 1u < tiles;
+                    const uint32_t rn = more ? r : (r + n_waves < n_items ? r + n_waves : r);
+                    const uint32_t sn = more ? s + 16u : c;
+                    load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
+                }
+                const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(now), a);
+                const float sigma = last_act(act, z4);
+                if (valid && g == 0u)
+                    part += sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);     // the 16 points of lane group 0
+            if (lane == 0) out[r] = part;
+        }
+    } else {
+        const uint32_t tiles = (n_items + 15u) / 16u;
+        for (uint32_t k = wave; k < tiles; k += n_waves) {
+            const uint32_t p0 = 16u * k + c;
+            const bool valid = p0 < n_items;
+            const uint32_t p = valid ? p0 : n_items - 1u;
+            Feat16Raw raw;
+            load_feat16(feat, B, p, g, raw);
+            const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(raw), a);
+            if (valid && g == 0u) out[p] = last_act(act, z4);
         }
     }
 }
@@ -370,6 +427,219 @@ loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target
     }
 }
 
+// ---- 3b: MLP backward on 16-point tiles (bf16 mode, C = 2; field_mlp16.h) ----------------------------------------
+// Same outputs as mlp_backward_kernel (dfeat, one dW slab per workgroup, max |dfeat|) at two or more waves per SIMD.
+__global__ void __launch_bounds__(256, 2)
+mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
+                      const float *__restrict__ grad_acc, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
+                      uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Mlp16Shared::build(smem, mlp, 8);
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
+    // wave-uniform values are made scalar explicitly: the ray record, its depths range and d acc then live in SGPRs
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
+    constexpr uint32_t kShAligned = (Mlp16Shared::kBytes + 15u) & ~15u;
+    constexpr uint32_t kImg = 16u * 64u;                                           // bytes per transpose image
+    unsigned char *imgG = smem + kShAligned + wib * 3u * kImg;                     // gradient tile G3 / G2 / G1
+    unsigned char *imgX = imgG + kImg;                                             // input tile X0
+    unsigned char *imgH = imgX + kImg;                                             // hidden tile H2 / H1
+    float *zbuf = reinterpret_cast<float *>(smem + kShAligned + 4u * 3u * kImg) + wib * kMaxSamplesLds;
+    const bool use_zbuf = src.S <= kMaxSamplesLds;
+
+    // weight-gradient accumulators: tile (o, q) covers outputs 16o.. and inputs 16q..; lane (col, grp), register i
+    // <-> dW[out = 16 o + 4 grp + i][in = 16 q + col]
+    const f32x4v zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4v dW0[2][2], dW1[2][2], dW2[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { dW0[o][q] = zero4; dW1[o][q] = zero4; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dW2[o][q] = zero4;
+    }
+    float db[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};                 // per lane: output 16o + (lane & 15), its 4 points
+    float db3 = 0.0f, dmax = 0.0f;
+    f32x4v dw3lo = zero4, dw3hi = zero4;
+
+    const uint32_t S = src.S, tiles = (S + 15u) / 16u;
+    Feat16Raw ahead;
+    if (wave < n_rays) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
+    for (uint32_t r = wave; r < n_rays; r += n_waves) {
+        const float *ray = src.rays + (size_t)r * 8;
+        const float near = ray[6], far = ray[7];
+        const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+        const float dacc = grad_acc[r];
+        if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
+
+        for (uint32_t k = 0; k < tiles; ++k) {
+            const uint32_t s = 16u * k + c;
+            const bool valid = s < S;
+            const uint32_t p = r * S + (valid ? s : S - 1u);
+            const Feat16Raw now = ahead;
+            {
+                const bool more = k + 1u < tiles;
+                const uint32_t rn = more ? r : (r + n_waves < n_rays ? r + n_waves : r);
+                const uint32_t sn = more ? s + 16u : c;
+                load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
+            }
+            const bf16x8 x0f = feat16_operand(now);
+            // Weight fragments and biases are re-read from LDS for every tile: hoisted out of the loop (which the compiler
+            // does when it can prove the addresses loop-invariant) they would pin ~90 registers and halve the occupancy.
+            uint32_t tile_tag = 0;
+            asm volatile("" : "+v"(tile_tag));
+            const unsigned char *wsh = smem + tile_tag;
+            Act16 a;
+            const float z4 = mlp16_tile_forward(wsh, lane, x0f, a);
+            const float sigma = last_act(act, z4);
+            const float gsig = !valid ? 0.0f
+                             : dacc * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+            const float g4 = gsig * last_act_grad(act, z4, sigma);
+
+            // output layer: dw3 += g4 * h3, db3 += g4 ; G3 = (w3 g4) * lrelu'(z3)
+            f32x4v glo, ghi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dw3lo[j] = __fmaf_rn(g4, a.h3lo[j], dw3lo[j]);
+                dw3hi[j] = __fmaf_rn(g4, a.h3hi[j], dw3hi[j]);
+                glo[j] = a.w3lo[j] * g4 * (a.h3lo[j] > 0.0f ? 1.0f : kLeaky);
+                ghi[j] = a.w3hi[j] * g4 * (a.h3hi[j] > 0.0f ? 1.0f : kLeaky);
+            }
+            if (g == 0u) db3 += g4;
+
+            // layer 2: dW2 = G3 . [X0; H2]^T over the 16 points of the tile
+            bf16x8 gf = pack16(glo, ghi);
+            tr16_put(imgG, c, g, gf);
+            tr16_put(imgX, c, g, x0f);
+            tr16_put(imgH, c, g, a.h2f);
+            wave_lds_fence<PrecBF16>();
+            i16x4v gA[2], xB[2], hB[2];
+#pragma unroll
+            for (uint32_t o = 0; o < 2; ++o) { gA[o] = tr16_get(imgG, lane, o); xB[o] = tr16_get(imgX, lane, o); hB[o] = tr16_get(imgH, lane, o); }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                dW2[o][0] = mma16k16(gA[o], xB[0], dW2[o][0]);
+                dW2[o][1] = mma16k16(gA[o], xB[1], dW2[o][1]);
+                dW2[o][2] = mma16k16(gA[o], hB[0], dW2[o][2]);
+                dW2[o][3] = mma16k16(gA[o], hB[1], dW2[o][3]);
+                db[2][o] += sum_bf16x4(gA[o]);
+            }
+            wave_lds_fence<PrecBF16>();
+
+            // back through layer 2 (skip layer): d[input] and d[h2]
+            f32x4v dxlo = mma16(Mlp16Shared::frag(wsh, kFW2aT, 0, lane), gf, zero4);
+            f32x4v dxhi = mma16(Mlp16Shared::frag(wsh, kFW2aT, 1, lane), gf, zero4);
+            f32x4v dhlo = mma16(Mlp16Shared::frag(wsh, kFW2bT, 0, lane), gf, zero4);
+            f32x4v dhhi = mma16(Mlp16Shared::frag(wsh, kFW2bT, 1, lane), gf, zero4);
+            glo = leaky_grad4_packed(dhlo, a.h2f, 0);                              // G2
+            ghi = leaky_grad4_packed(dhhi, a.h2f, 1);
+            gf = pack16(glo, ghi);
+            tr16_put(imgG, c, g, gf);
+            tr16_put(imgH, c, g, a.h1f);
+            wave_lds_fence<PrecBF16>();
+#pragma unroll
+            for (uint32_t o = 0; o < 2; ++o) { gA[o] = tr16_get(imgG, lane, o); hB[o] = tr16_get(imgH, lane, o); }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                dW1[o][0] = mma16k16(gA[o], hB[0], dW1[o][0]);
+                dW1[o][1] = mma16k16(gA[o], hB[1], dW1[o][1]);
+                db[1][o] += sum_bf16x4(gA[o]);
+            }
+            wave_lds_fence<PrecBF16>();
+
+            dhlo = mma16(Mlp16Shared::frag(wsh, kFW1T, 0, lane), gf, zero4);
+            dhhi = mma16(Mlp16Shared::frag(wsh, kFW1T, 1, lane), gf, zero4);
+            glo = leaky_grad4_packed(dhlo, a.h1f, 0);                              // G1
+            ghi = leaky_grad4_packed(dhhi, a.h1f, 1);
+            gf = pack16(glo, ghi);
+            tr16_put(imgG, c, g, gf);
+            wave_lds_fence<PrecBF16>();
+#pragma unroll
+            for (uint32_t o = 0; o < 2; ++o) { gA[o] = tr16_get(imgG, lane, o); xB[o] = tr16_get(imgX, lane, o); }   // X0 again: cheaper than keeping it
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                dW0[o][0] = mma16k16(gA[o], xB[0], dW0[o][0]);
+                dW0[o][1] = mma16k16(gA[o], xB[1], dW0[o][1]);
+                db[0][o] += sum_bf16x4(gA[o]);
+            }
+            wave_lds_fence<PrecBF16>();
+
+            dxlo = mma16(Mlp16Shared::frag(wsh, kFW0T, 0, lane), gf, dxlo);
+            dxhi = mma16(Mlp16Shared::frag(wsh, kFW0T, 1, lane), gf, dxhi);
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dmax = fmaxf(dmax, fmaxf(fabsf(dxlo[j]), fabsf(dxhi[j])));
+                const uint4 o4 = __builtin_bit_cast(uint4, pack16(dxlo, dxhi));
+                uint32_t *df = reinterpret_cast<uint32_t *>(dfeat);
+                df[(size_t)(2u * g) * B + p] = o4.x;
+                df[(size_t)(2u * g + 1u) * B + p] = o4.y;
+                df[(size_t)(8u + 2u * g) * B + p] = o4.z;
+                df[(size_t)(9u + 2u * g) * B + p] = o4.w;
+            }
+        }
+    }
+
+    if (gmax_bits != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if (lane == 0 && dmax > 0.0f) atomicMax(gmax_bits, __float_as_uint(dmax));      // positive floats order like uints
+    }
+
+    // ---- fold the 4 waves of the workgroup into one slab (wave order -> deterministic), then one store ---------------
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {                                               // over the four point groups of an output
+            db[l][o] += __shfl_xor(db[l][o], 16, 64);
+            db[l][o] += __shfl_xor(db[l][o], 32, 64);
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {                                         // over the 16 points of a lane group
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dw3lo[j] += __shfl_xor(dw3lo[j], off, 64); dw3hi[j] += __shfl_xor(dw3hi[j], off, 64); }
+        db3 += __shfl_xor(db3, off, 64);
+    }
+    __syncthreads();                                                                // images / depth buffers are dead
+    float *red = reinterpret_cast<float *>(smem + kShAligned);
+    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) red[i] = 0.0f;
+    __syncthreads();
+    for (uint32_t w = 0; w < 4u; ++w) {
+        if (wib == w) {
+#pragma unroll
+            for (uint32_t o = 0; o < 2; ++o)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint32_t out = 16u * o + 4u * g + i;
+#pragma unroll
+                    for (uint32_t q = 0; q < 2; ++q) {
+                        red[kW0 + out * 32u + 16u * q + c] += dW0[o][q][i];
+                        red[kW1 + out * 32u + 16u * q + c] += dW1[o][q][i];
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) red[kW2 + out * 64u + 16u * q + c] += dW2[o][q][i];
+                }
+            if (g == 0u) {
+#pragma unroll
+                for (uint32_t o = 0; o < 2; ++o) {
+                    red[kB0 + 16u * o + c] += db[0][o];
+                    red[kB1 + 16u * o + c] += db[1][o];
+                    red[kB2 + 16u * o + c] += db[2][o];
+                }
+            }
+            if (c == 0u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    red[kW3 + 4u * g + j] += dw3lo[j];
+                    red[kW3 + 16u + 4u * g + j] += dw3hi[j];
+                }
+            }
+            if (lane == 0u) red[kB3] += db3;
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
+    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) slab[i] = red[i];
+}
+
 // ---- 5: slabs -> grad_mlp (+=), summed in a fixed order (deterministic) ---------------------------------------
 // 256 threads = 32 parameters x 8 slab groups: group g adds slabs g, g+8, ... (four independent chains), the eight
 // partial sums are combined through LDS in group order.
@@ -402,6 +672,12 @@ mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float 
 
 // ---- host side ----------------------------------------------------------------------------------------------
 constexpr uint32_t kBackwardBlocks = 512;   // 2 workgroups of 4 waves per CU; also the number of dW slabs
+
+// 16-point-tile MLP kernels (bf16 mode, C = 2); NAF_MLP16=0 selects the 32-point kernels for comparison
+static inline bool use_mlp16() {
+    static const bool on = [] { const char *e = std::getenv("NAF_MLP16"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 template <typename P>
 static uint32_t forward_lds_bytes() { return ((MlpShared<P>::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u; }
@@ -583,6 +859,16 @@ static int dispatch_encode(const Src &src, const void *table, const int32_t *off
 template <typename P, uint32_t C, bool kRays>
 static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &src, float *out, uint32_t n_items, uint32_t B,
                            const naf_render_cfg *cfg, hipStream_t s) {
+    if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
+        if (use_mlp16()) {
+            const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u;
+            const uint64_t waves16 = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
+            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves16 + 3) / 4, 256u * 8u));
+            { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL((mlp16_forward_kernel<kRays>), dim3(grid16), dim3(256), lds16, s,
+                               (const uint16_t *)feat, mlp, src, out, n_items, B, cfg->last_activation); }
+            return check_launch("mlp16_forward_kernel");
+        }
+    }
     auto kern = mlp_forward_kernel<P, C, kRays>;
     const uint32_t lds = forward_lds_bytes<P>();
     const uint64_t waves_needed = kRays ? n_items : ((uint64_t)n_items + 31) / 32;
@@ -596,6 +882,19 @@ template <typename P, uint32_t C>
 static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, void *dfeat,
                             float *slabs, uint32_t *gmax_bits, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg,
                             hipStream_t s) {
+    if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
+        if (use_mlp16()) {
+            const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
+            const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
+            if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
+            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
+            { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
+                               grad_acc, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
+            if (int rc = check_launch("mlp16_backward_kernel")) return rc;
+            { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + kReduceParams - 1) / kReduceParams), dim3(256), 0, s, slabs, grid16, grad_mlp); }
+            return check_launch("mlp_grad_reduce_kernel");
+        }
+    }
     auto kern = mlp_backward_kernel<P, C>;
     const uint32_t lds = backward_lds_bytes<P>();
     static bool attr_set = false;       // raise the dynamic-LDS cap once per instantiation (fp32 images need > 64 KiB)
