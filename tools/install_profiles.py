@@ -44,8 +44,8 @@ traffic = {
     "bf16": {
         "hash_forward": hbm("encode_kernel"),
         "hash_backward": hbm("scatter_bin_kernel") + hbm("scatter_reduce_kernel"),
-        "mlp_forward": hbm("mlp_forward_kernel"),
-        "mlp_backward": hbm("mlp_backward_kernel"),
+        "mlp_forward": hbm("mlp_forward_kernel") + hbm("mlp16_forward_kernel"),
+        "mlp_backward": hbm("mlp_backward_kernel") + hbm("mlp16_backward_kernel"),
     },
 }
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
@@ -65,14 +65,14 @@ def counters(*files):
         if not os.path.exists(path):
             continue
         for r in csv.DictReader(open(path)):
-            name = re.sub(r"<.*", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("naf::", "")
+            name = re.sub(r"[<(].*", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("naf::", "")
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 
 
 sq = counters("sqa/sqa_counter_collection.csv", "sqb/sqb_counter_collection.csv")
 mf = counters("mfma/mfma_counter_collection.csv")
-kernels = ("encode_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "scatter_apply_kernel")
+kernels = ("encode_kernel", "mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "scatter_apply_kernel")
 out = ["# Counter evidence per kernel (MI355X, chest_50 bf16, 65 536 rays/step = 12.58 M points; tools/collect_profiles.sh)", "",
        "## Dynamic instruction mix", "",
        "`rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0`,",
@@ -90,7 +90,7 @@ for k in kernels:
 out += ["", "## MFMA utilisation of the MLP kernels", "",
         "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0`", "",
         "| kernel | SQ_INSTS_MFMA | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CU_CYCLES | MFMA busy / (4 SIMD x CU busy) |", "|---|---|---|---|---|"]
-for k in ("mlp_forward_kernel", "mlp_backward_kernel"):
+for k in ("mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel"):
     row = mf.get(k)
     if not row:
         continue
