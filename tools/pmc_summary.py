@@ -29,7 +29,7 @@ for f in files:
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
 for k, cs in sorted(agg.items()):
-    if not any(s in k for s in ("encode", "scatter", "mlp_", "adam", "hash_")):
+    if not any(s in k for s in ("encode", "scatter", "mlp", "adam", "hash_")):
         continue
     row = {c: sum(v) / len(v) * 1024 for c, v in cs.items()}
     row["dispatches"] = max(len(v) for v in cs.values())
