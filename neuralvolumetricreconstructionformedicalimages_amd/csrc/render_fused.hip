@@ -955,10 +955,10 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
           // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles
           const uint32_t n_split = std::max(1u, std::min(16u, 1024u / (NB * nl)));
           hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                             grad_table, w.sums, w.gmax, l0, plan);
+                             grad_table, w.sums, w.gmax, cfg->H, l0, plan);
           if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
               hipLaunchKernelGGL((scatter_apply_kernel<C>), dim3((plan.max_local_rows + 63u) / 64u, nl, NB / 64u), dim3(256), 0, s,
-                                 w.sums, offsets, grad_table, l0, plan); }
+                                 w.sums, offsets, grad_table, cfg->H, l0, plan); }
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }
     return NAF_OK;

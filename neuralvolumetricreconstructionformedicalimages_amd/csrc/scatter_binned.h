@@ -93,12 +93,15 @@ __device__ __forceinline__ long long to_fixed(float v, double scale) {
 // uint32-wrapped dense levels row = x + s1 y + s2 z with s1 = s2 = 1 (mod 64): with the plain low bits the eight corners
 // of a cell fall into buckets b + {0,1,1,2,1,2,2,3}, and the triple hits overflow the staging runs (0.5 ms per step of
 // fallback atomics); rotated they fall into b + {0,1,2,3,3,4,5,6}.
+// Hashed levels scatter their rows anyway and skip the rotation (three VALU operations per record in pass 1): `twist` is 1
+// on dense / wrapped-dense levels, 0 on hashed ones -- the same rule in all three passes (level_twist).
 __device__ __forceinline__ uint32_t bucket_twist(uint32_t local) { return local + (local >> 10); }
-__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb) {
-    return (row + bucket_twist(row >> log2_nb)) & ((1u << log2_nb) - 1u);
+__device__ __forceinline__ uint32_t level_twist(const LevelMeta &m) { return m.mode < kHashMask ? 1u : 0u; }
+__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb, uint32_t twist) {
+    return (row + (twist ? bucket_twist(row >> log2_nb) : 0u)) & ((1u << log2_nb) - 1u);
 }
-__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb) {
-    return (local << log2_nb) | ((bucket - bucket_twist(local)) & ((1u << log2_nb) - 1u));
+__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb, uint32_t twist) {
+    return (local << log2_nb) | ((bucket - (twist ? bucket_twist(local) : 0u)) & ((1u << log2_nb) - 1u));
 }
 
 // rows per bucket in the sums buffer of pass 2 (a multiple of 64: pass 3 works on 64-row blocks)
@@ -199,11 +202,15 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
         if (emit) {
             uint32_t pos[8], bkt[8];
+            if (level_twist(m)) {                                     // wave-uniform
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) {
-                bkt[c] = bucket_of(row[c], plan.log2_nb);
-                pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
+                for (uint32_t c = 0; c < 8; ++c) bkt[c] = bucket_of(row[c], plan.log2_nb, 1u);
+            } else {
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c) bkt[c] = bucket_of(row[c], plan.log2_nb, 0u);
             }
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
 #pragma unroll
             for (uint32_t c = 0; c < 8; ++c) {
                 if (pos[c] < CAP) {
@@ -278,7 +285,7 @@ template <uint32_t C, typename Rec>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, float *__restrict__ sums, const uint32_t *__restrict__ gmax_bits,
-                      uint32_t level_base, BinPlan plan) {
+                      uint32_t H, uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int shift = fixed_shift(*gmax_bits);
     const double scale = ldexp(1.0, shift);
@@ -288,7 +295,8 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
     const uint32_t full_groups = T >> plan.log2_nb;
-    const uint32_t rows_local = full_groups + (row_of(bucket, full_groups, plan.log2_nb) < T ? 1u : 0u);
+    const uint32_t twist = level_twist(make_level_meta<3>(offsets, level, H));
+    const uint32_t rows_local = full_groups + (row_of(bucket, full_groups, plan.log2_nb, twist) < T ? 1u : 0u);
     // accumulators are channel-major, acc[ch][local row]: the two 8-byte cells of a row would otherwise sit 8 bytes apart and
     // one ds_add_u64 instruction (one channel of 64 rows) could reach only every other bank pair
     const uint32_t pitch = plan.max_local_rows;
@@ -372,7 +380,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         float *__restrict__ gg = grad_table + (size_t)off * C;
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb) * C + ch,
+            atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb, twist) * C + ch,
                       (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));             // one add per row and split
         }
     }
@@ -386,13 +394,14 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 template <uint32_t C>
 __global__ void __launch_bounds__(256)
 scatter_apply_kernel(const float *__restrict__ sums, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
-                     uint32_t level_base, BinPlan plan) {
+                     uint32_t H, uint32_t level_base, BinPlan plan) {
     __shared__ float tile[64][64 * C + 1];                      // [bucket in group][local in block][C], odd pitch
     const uint32_t ly = blockIdx.y, level = level_base + ly, local0 = blockIdx.x * 64u, bucket0 = blockIdx.z * 64u;
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     if (((size_t)local0 << plan.log2_nb) >= T) return;          // block past the end of this level (uniform)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const size_t rows = sums_rows(plan);
+    const uint32_t twist = level_twist(make_level_meta<3>(offsets, level, H));
     for (uint32_t b = wave; b < 64u; b += 4u) {
         const float *src_b = sums + ((((size_t)ly << plan.log2_nb) + bucket0 + b) * rows + local0) * C;
 #pragma unroll
@@ -401,7 +410,7 @@ scatter_apply_kernel(const float *__restrict__ sums, const int32_t *__restrict__
     __syncthreads();
     float *__restrict__ gg = grad_table + (size_t)off * C;
     for (uint32_t j = wave; j < 64u; j += 4u) {
-        const uint32_t row = row_of(bucket0 + lane, local0 + j, plan.log2_nb);
+        const uint32_t row = row_of(bucket0 + lane, local0 + j, plan.log2_nb, twist);
         if (row < T) {
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ++ch) gg[(size_t)row * C + ch] += tile[lane][j * C + ch];
