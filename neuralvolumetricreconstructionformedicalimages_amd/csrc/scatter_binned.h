@@ -255,7 +255,14 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                     const uint32_t bkt = base + NW * k;
                     const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
                     if (bkt < NB && 2u * lane < min((nrun[k] + 15u) & ~15u, CAP)) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // whole 128-byte lines; stale slots are harmless
-                    if (bkt < NB && lane == 0u) counts[count_index(plan, ly, bkt, tile)] = nrun[k];
+                }
+                // the kCopy run lengths of the batch leave with ONE store: lane k writes the count of bucket base + NW k
+                if (lane < kCopy) {
+                    uint32_t mine = nrun[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < kCopy; ++k) mine = lane == k ? nrun[k] : mine;
+                    const uint32_t bkt = base + NW * lane;
+                    if (bkt < NB) counts[count_index(plan, ly, bkt, tile)] = mine;
                 }
             }
         } else {
