@@ -201,26 +201,31 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         }
         // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
         if (emit) {
-            uint32_t pos[8], bkt[8];
-            if (level_twist(m)) {                                     // wave-uniform
+            const uint32_t twist = level_twist(m);                      // wave-uniform
 #pragma unroll
-                for (uint32_t c = 0; c < 8; ++c) bkt[c] = bucket_of(row[c], plan.log2_nb, 1u);
-            } else {
+            for (uint32_t half = 0; half < 2; ++half) {                 // four corners at a time: fewer live registers
+                uint32_t pos[4], bkt[4];
+                if (twist) {
 #pragma unroll
-                for (uint32_t c = 0; c < 8; ++c) bkt[c] = bucket_of(row[c], plan.log2_nb, 0u);
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
-#pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) {
-                if (pos[c] < CAP) {
-                    Rec r;
-                    r.set(row[c] >> plan.log2_nb, val[c]);
-                    staging[bkt[c] * CAP + pos[c]] = r;
+                    for (uint32_t c = 0; c < 4; ++c) bkt[c] = bucket_of(row[4 * half + c], plan.log2_nb, 1u);
                 } else {
 #pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[c] * C + ch, val[c][ch]);
-                    ++n_overflow;
+                    for (uint32_t c = 0; c < 4; ++c) bkt[c] = bucket_of(row[4 * half + c], plan.log2_nb, 0u);
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t cc = 4 * half + c;
+                    if (pos[c] < CAP) {
+                        Rec r;
+                        r.set(row[cc] >> plan.log2_nb, val[cc]);
+                        staging[bkt[c] * CAP + pos[c]] = r;
+                    } else {
+#pragma unroll
+                        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[cc] * C + ch, val[cc][ch]);
+                        ++n_overflow;
+                    }
                 }
             }
         }
