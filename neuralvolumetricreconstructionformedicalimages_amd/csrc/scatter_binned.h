@@ -244,30 +244,28 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         //    (slot_cap even, <= 128).  The other counter set is cleared for the next level meanwhile.
         for (uint32_t i = threadIdx.x; i < NB; i += NT) cnt2[((it & 1u) ^ 1u) * NB + i] = 0u;
         if constexpr (sizeof(Rec) == 8) {
-            constexpr uint32_t kCopy = 4;
+            constexpr uint32_t kCopy = 4;                              // NB (>= 64, a power of two) is a multiple of NW * kCopy
             const uint32_t pairs = CAP >> 1;
             const uint32_t my_pair = min(lane, pairs - 1u);     // (slot_cap is a multiple of 16 records = 128 B here)
+            Rec *__restrict__ tile_regions = regions + region_index(plan, ly, 0u, tile) * CAP;      // the NB regions of this tile are adjacent
             for (uint32_t base = wave; base < NB; base += NW * kCopy) {
                 uint32_t nrun[kCopy];
                 uint4 v[kCopy];
 #pragma unroll
-                for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[min(base + NW * k, NB - 1u)], CAP);
+                for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[base + NW * k], CAP);
 #pragma unroll
                 for (uint32_t k = 0; k < kCopy; ++k)
-                    v[k] = reinterpret_cast<const uint4 *>(staging + min(base + NW * k, NB - 1u) * CAP)[my_pair];
+                    v[k] = reinterpret_cast<const uint4 *>(staging + (base + NW * k) * CAP)[my_pair];
 #pragma unroll
-                for (uint32_t k = 0; k < kCopy; ++k) {
-                    const uint32_t bkt = base + NW * k;
-                    const size_t reg = region_index(plan, ly, min(bkt, NB - 1u), tile);
-                    if (bkt < NB && 2u * lane < min((nrun[k] + 15u) & ~15u, CAP)) reinterpret_cast<uint4 *>(regions + reg * CAP)[lane] = v[k];   // whole 128-byte lines; stale slots are harmless
-                }
+                for (uint32_t k = 0; k < kCopy; ++k)
+                    if (2u * lane < min((nrun[k] + 15u) & ~15u, CAP))        // whole 128-byte lines; stale slots are harmless
+                        reinterpret_cast<uint4 *>(tile_regions + (size_t)(base + NW * k) * CAP)[lane] = v[k];
                 // the kCopy run lengths of the batch leave with ONE store: lane k writes the count of bucket base + NW k
                 if (lane < kCopy) {
                     uint32_t mine = nrun[0];
 #pragma unroll
                     for (uint32_t k = 1; k < kCopy; ++k) mine = lane == k ? nrun[k] : mine;
-                    const uint32_t bkt = base + NW * lane;
-                    if (bkt < NB) counts[count_index(plan, ly, bkt, tile)] = mine;
+                    counts[count_index(plan, ly, base + NW * lane, tile)] = mine;
                 }
             }
         } else {
