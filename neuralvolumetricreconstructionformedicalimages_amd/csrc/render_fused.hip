@@ -182,7 +182,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Mlp16Shared::build(smem, mlp, 4);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
     Act16 a;
     if constexpr (kRays) {
         const uint32_t S = src.S, tiles = (S + 15u) / 16u;

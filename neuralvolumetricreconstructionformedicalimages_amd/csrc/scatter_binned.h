@@ -131,7 +131,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     const uint32_t NB = 1u << plan.log2_nb, CAP = plan.slot_cap;
     uint32_t *cnt2 = reinterpret_cast<uint32_t *>(smem);
     Rec *staging = reinterpret_cast<Rec *>(cnt2 + 2u * NB);
-    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: copy-out bucket arithmetic on the SALU
     for (uint32_t i = threadIdx.x; i < 2u * NB; i += NT) cnt2[i] = 0u;
 
     // the thread's point.  Threads past the end of the batch take the last point with a zero gradient: their records
@@ -313,7 +313,8 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = T_ >> 6;
+    // the wave index is made scalar explicitly: tile ranges, run-length block addresses and region bases then live in SGPRs
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = T_ >> 6;
     const size_t cnt0 = count_index(plan, ly, bucket, 0);
     auto add = [&](const Rec &r) {
 #pragma unroll
