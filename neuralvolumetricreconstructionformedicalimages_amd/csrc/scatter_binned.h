@@ -340,11 +340,11 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) {
                 const uint32_t tj = min(j + u, n_here - 1u);
-                n[u] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
+                n[u] = j + u < n_here ? (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)tj) : 0u;      // scalar (tj is wave-uniform)
                 n_max = max(n_max, n[u]);
                 ra[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
             }
-            if ((uint32_t)__builtin_amdgcn_readfirstlane(n_max) <= 64u + kTail) {
+            if (n_max <= 64u + kTail) {
                 // the usual case: no run is longer than 64 + kTail records.  The tails (records 64..) of 64 / kTail regions
                 // share one load and one pair of LDS atomics, kTail lanes per region, instead of a nearly empty wave each.
                 constexpr uint32_t kPer = 64u / kTail;                      // regions per tail instruction
