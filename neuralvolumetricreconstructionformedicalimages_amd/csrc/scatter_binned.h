@@ -352,9 +352,11 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
                 uint32_t nt[kGroup / kPer];
 #pragma unroll
                 for (uint32_t q = 0; q < kGroup / kPer; ++q) {
-                    const uint32_t u = q * kPer + lane / kTail, slot = 64u + (lane % kTail);
+                    const uint32_t sub = lane / kTail, u = q * kPer + sub, slot = 64u + (lane % kTail);
                     const uint32_t tj = min(j + u, n_here - 1u);
-                    nt[q] = j + u < n_here ? (uint32_t)__shfl(mine, (int)tj, 64) : 0u;
+                    nt[q] = n[q * kPer];                                    // select among the kPer scalar run lengths
+#pragma unroll
+                    for (uint32_t k = 1; k < kPer; ++k) nt[q] = sub == k ? n[q * kPer + k] : nt[q];
                     rt[q] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[slot < nt[q] ? slot : 0u];
                 }
 #pragma unroll
