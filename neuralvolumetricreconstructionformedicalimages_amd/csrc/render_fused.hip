@@ -405,13 +405,18 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
 }
 
 // masked squared error of train.py:127 / loss.py:37 in weighted form: loss = sum_r w_r (acc_r - y_r)^2,
-// grad_acc[r] = 2 w_r (acc_r - y_r).  One workgroup; the sum runs in a fixed order (deterministic).
+// grad_acc[r] = 2 w_r (acc_r - y_r).  Each workgroup takes a contiguous slice of the rays and leaves its partial sum in
+// partial[blockIdx.x]; loss_sum_kernel adds the partials in index order (deterministic).  One workgroup (small batches)
+// adds straight into loss_out.
+constexpr uint32_t kLossBlocks = 64;
 __global__ void __launch_bounds__(1024)
 loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target, const float *__restrict__ ray_weight,
-                 float *__restrict__ grad_acc, float *__restrict__ loss_out, uint32_t n_rays) {
+                 float *__restrict__ grad_acc, float *__restrict__ loss_out, float *__restrict__ partial, uint32_t n_rays) {
     __shared__ float part[16];
+    const uint32_t per_block = (n_rays + gridDim.x - 1u) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per_block, end = min(n_rays, begin + per_block);
     float s = 0.0f;
-    for (uint32_t r = threadIdx.x; r < n_rays; r += blockDim.x) {
+    for (uint32_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
         const float err = acc[r] - target[r], w = ray_weight[r];
         grad_acc[r] = 2.0f * w * err;
         s += w * err * err;
@@ -420,9 +425,18 @@ loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_out != nullptr) {
+    if (threadIdx.x == 0) {
         float t = 0.0f;
         for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) t += part[i];
+        if (gridDim.x == 1u) { if (loss_out != nullptr) loss_out[0] += t; }
+        else partial[blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(64)
+loss_sum_kernel(const float *__restrict__ partial, uint32_t n, float *__restrict__ loss_out) {
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) t += partial[i];
         loss_out[0] += t;
     }
 }
@@ -746,7 +760,7 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
     w.dfeat = w.feat + feat_bytes;
     w.slabs = (float *)(w.dfeat + feat_bytes);
     w.grad_acc = (float *)((unsigned char *)w.slabs + slab_bytes);
-    w.bytes = 2 * feat_bytes + slab_bytes + ((n_rays_max * 4 + 255) & ~(size_t)255);
+    w.bytes = 2 * feat_bytes + slab_bytes + ((n_rays_max * 4 + 255) & ~(size_t)255) + 512;      // + partial sums of the loss
     w.binned = make_bin_plan(cfg, n_points, &w.plan);
     w.regions = nullptr;
     w.counts = nullptr;
@@ -1036,7 +1050,13 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
     const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
-    { ProfScope prof_("loss_grad_kernel", s); hipLaunchKernelGGL(loss_grad_kernel, dim3(1), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, n_rays); }
+    {   // the partial sums live behind grad_acc in the workspace (carve reserves 256 bytes for them)
+        float *partial = w.grad_acc + (((size_t)n_rays + 63) & ~(size_t)63);
+        const uint32_t blocks = n_rays >= 16384u ? kLossBlocks : 1u;
+        ProfScope prof_("loss_grad_kernel", s);
+        hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, partial, n_rays);
+        if (blocks > 1u && loss_out != nullptr) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, blocks, loss_out);
+    }
     if (int rc = check_launch("loss_grad_kernel")) return rc;
     return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, s);
 }
