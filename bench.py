@@ -3,18 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = ray generation for one batch of pixels + fused render forward + masked MSE + backward (MLP + hash-table
-scatter) + gradient all-reduce (N > 1) + Adam over the table and the MLP, i.e. `Trainer.train_step` of the reference
-(src/trainer.py:134-142 around train.py:48-135) on chest_50.yaml: 256^3 volume, 50 cone-beam projections of
-512x512, L=16 T=2^19 C=2 hash grid stored in bf16, S=192 samples per ray, synthetic phantom with analytic
-projections (the reference ships no data).  Inputs (poses, pixel indices, targets) are resident in HBM before the
-timed region.  Prints ONE JSON line on rank 0.
+A step = what `Trainer.train_step` of the reference does for one batch (src/trainer.py:134-142 around train.py:48-135,
+data side src/dataset/tigre.py:354-372), all of it inside the timed region and none of it touching the host:
+    draw distinct valid pixels of the step's projections on the device -> gather their measured values ->
+    cone-beam ray generation -> fused render forward -> masked MSE -> backward (MLP + hash-table scatter) ->
+    bucketed gradient all-reduce overlapped with the scatter (N > 1) -> Adam over the table and the MLP.
+Workload: chest_50.yaml -- 256^3 volume, 50 cone-beam projections of 512x512, L=16 T=2^19 C=2 hash grid stored in bf16,
+S=192 samples per ray, synthetic phantom with analytic projections (the reference ships no data).  The scan (poses,
+projections, per-projection valid-pixel lists) is resident in HBM before the clock starts.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,8 +28,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 CHEST = dict(n_voxel=256, n_proj=50, n_samples=192, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
-             bound=0.3, lr=1e-3)
+             bound=0.3, lr=1e-3, yaml_rays=1024)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RAYS_PER_PROJECTION = 16384    # a step of n rays draws from n / 16384 consecutive projections (the YAML step: 1024 from one)
 
 
 def algorithmic_bytes_per_point(kernel, table_bytes, feat_bytes, L=16, C=2, D=3):
@@ -40,9 +44,11 @@ def algorithmic_bytes_per_point(kernel, table_bytes, feat_bytes, L=16, C=2, D=3)
     raise KeyError(kernel)
 
 
-def cpu_baseline(seconds, n_rays, seed=0):
-    """The oracle's pure-PyTorch CPU training step (the reference has no CPU hash encoder: SURVEY.md 8c/8d),
-    same chest_50 shapes, fp32, all host threads.  Bounded: warm-up + as many steps as fit in `seconds`."""
+def cpu_baseline(seconds, seed=0):
+    """The oracle's pure-PyTorch CPU training step (the reference has no CPU hash encoder: SURVEY.md 8c/8d), chest_50
+    shapes, fp32, the job's host threads.  Protocol of BASELINE.md section 3 -- 3 warm-up + 10 timed optimiser steps,
+    median, at 1 024 and 8 192 rays per step -- cut short where the time budget runs out (the report says how many steps
+    were timed): the 1 024-ray leg may use 60 % of `seconds`, the 8 192-ray leg the rest (at least one timed step each)."""
     from oracle.hashgrid_ref import HashEncoderRef
     from oracle.network_ref import DensityNetworkRef
     from oracle import render_ref as R
@@ -54,35 +60,81 @@ def cpu_baseline(seconds, n_rays, seed=0):
     net = DensityNetworkRef(enc, bound=CHEST["bound"], num_layers=4, hidden_dim=32, skips=(2,), out_dim=1)
     opt = torch.optim.Adam(net.parameters(), lr=CHEST["lr"], betas=(0.9, 0.999))
     g = torch.Generator().manual_seed(seed)
-    ang = torch.rand(n_rays, generator=g) * 3.1416
-    o = torch.stack([torch.cos(ang), torch.sin(ang), torch.zeros(n_rays)], -1)
-    tgt = (torch.rand(n_rays, 3, generator=g) - 0.5) * 0.25
-    d = tgt - o
-    rays = torch.cat([o, d, torch.full((n_rays, 1), 0.814), torch.full((n_rays, 1), 1.186)], -1)
-    target = torch.rand(n_rays, generator=g) * 0.1
 
-    def step():
+    def batch(n):
+        ang = torch.rand(n, generator=g) * 3.1416
+        o = torch.stack([torch.cos(ang), torch.sin(ang), torch.zeros(n)], -1)
+        d = (torch.rand(n, 3, generator=g) - 0.5) * 0.25 - o
+        rays = torch.cat([o, d, torch.full((n, 1), 0.814), torch.full((n, 1), 1.186)], -1)
+        return rays, torch.rand(n, generator=g) * 0.1
+
+    def step(rays, target):
         opt.zero_grad()
         acc = R.render(rays, net, None, CHEST["n_samples"], 0, True, 409600, 0.0)["acc"]
-        loss = ((acc - target) ** 2).mean()
-        loss.backward()
+        ((acc - target) ** 2).mean().backward()
         opt.step()
 
-    full = (rays, target)
-    rays, target = rays[:64], target[:64]
-    step()                                     # warm-up on a small batch (pages the table in, builds autograd caches)
-    rays, target = full
+    def leg(n, budget, warmups, want, est=None):
+        """Up to `warmups` untimed and `want` timed steps; whenever the remaining budget cannot hold the remaining plan,
+        warm-up steps are dropped first, then timed ones (never below one timed step)."""
+        rays, target = batch(n)
+        t_leg = time.perf_counter()
+        step(rays[:64], target[:64])                     # pages the table in, builds autograd caches
+        warm, times = 0, []
+        while len(times) < want:
+            left = budget - (time.perf_counter() - t_leg)
+            timing = warm >= warmups or (est is not None and left < (warmups - warm + 2) * est)
+            if timing and times and left < est:
+                break
+            t0 = time.perf_counter()
+            step(rays, target)
+            est = time.perf_counter() - t0
+            if timing:
+                times.append(est)
+            else:
+                warm += 1
+        med = statistics.median(times)
+        return {"rays_per_step": n, "warmup_steps": warm, "timed_steps": len(times), "median_step_s": round(med, 4),
+                "rays_per_s": n / med}
+
     t0 = time.perf_counter()
-    n = 0
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
-    return {"value": n * n_rays / el, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{n} optimiser steps of {n_rays} rays x {CHEST['n_samples']} samples (chest_50 shapes, fp32, "
-                      f"oracle/ pure-PyTorch path, torch {torch.__version__}) in {el:.1f} s"}
+    small = leg(1024, 0.6 * seconds, 3, 10)
+    big = leg(8192, max(seconds - (time.perf_counter() - t0), 1.0), 1, 10, est=8 * small["median_step_s"])
+    el = time.perf_counter() - t0
+    return {"value": small["rays_per_s"], "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"median of {small['timed_steps']} optimiser steps of 1024 rays x {CHEST['n_samples']} samples after "
+                      f"{small['warmup_steps']} warm-up steps (chest_50 shapes, fp32, oracle/ pure-PyTorch path, torch "
+                      f"{torch.__version__}); 8192-ray leg: median of {big['timed_steps']} steps; {el:.0f} s of CPU work in all",
+            "legs": [small, big]}
+
+
+class ScanSampler:
+    """The data side of a step on the device (tigre.py:354-372): distinct valid pixels of the step's projections, their
+    measured values, no host synchronisation.  Valid-pixel lists are found once per projection (the reference recomputes
+    `projs[index] > 0` for every item)."""
+
+    def __init__(self, projs, pixels_per_projection, generator):
+        self.projs = projs                                # [n_proj * H * W] fp32, resident
+        self.hw = pixels_per_projection
+        self.gen = generator
+        self.n_proj = projs.numel() // pixels_per_projection
+        self.valid = []
+        for i in range(self.n_proj):
+            flat = projs[i * self.hw:(i + 1) * self.hw]
+            self.valid.append(torch.nonzero(flat > 0, as_tuple=False).reshape(-1) + i * self.hw)
+
+    def draw(self, step, n):
+        per = min(n, RAYS_PER_PROJECTION)
+        k = (n + per - 1) // per
+        parts = []
+        for j in range(k):
+            valid = self.valid[(step * k + j) % self.n_proj]
+            m = min(per, n - j * per)
+            if valid.numel() < m:
+                raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+            parts.append(valid[torch.randperm(valid.numel(), device=valid.device, generator=self.gen)[:m]])
+        pixels = parts[0] if k == 1 else torch.cat(parts)
+        return pixels, self.projs[pixels]
 
 
 def main():
@@ -92,10 +144,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step (chest_50.yaml uses 1024)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16", help="table storage / MLP operand type")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables it)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the cpu_baseline leg (0 disables it)")
+    ap.add_argument("--sub-records", type=int, default=1, help="0: skip the fp32-parity-mode and 1024-ray sub-records (N = 1 only)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
-                    help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_set_scatter_mode)")
+                    help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_render_cfg.scatter_mode)")
+    ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
+                         "stream, per-bucket Adam) with a world-size-1 process group")
+    ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,0-8")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
@@ -117,53 +175,70 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29555")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     from neuralvolumetricreconstructionformedicalimages_amd import _abi, phantom
+    from neuralvolumetricreconstructionformedicalimages_amd.build import source_fingerprint
     from neuralvolumetricreconstructionformedicalimages_amd.encoder import HashEncoder
     from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
     from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
+    from neuralvolumetricreconstructionformedicalimages_amd.loss import chunk_mean_weights
     from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
 
-    _abi.check(_abi.lib().naf_set_scatter_mode({"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode]), "set_scatter_mode")
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    # ---- chest_50 scan: geometry, poses, phantom ----------------------------------------------------------------
+    # ---- chest_50 scan, resident in HBM: geometry, poses, all 50 x 512 x 512 measured values -----------------------
     geo = ConeGeometry(phantom.scan_geometry(CHEST["n_voxel"], "cone"))
     angles = np.linspace(0, np.pi, CHEST["n_proj"] + 1)[:-1]          # generateData.py:175, totalAngle 180
     raygen = RayGenerator(geo, angles, device)
     table = phantom.ellipsoid_table(seed=0, extent=float(geo.sVoxel[0]) / 2)
+    hw = raygen.pixels_per_projection
+    projs = torch.empty(raygen.n_projections * hw, device=device)
+    for i in range(raygen.n_projections):
+        r = raygen.rays_for_projection(i)
+        for j in range(0, hw, 1 << 16):
+            projs[i * hw + j:i * hw + j + (1 << 16)] = phantom.line_integrals(r[j:j + (1 << 16)], table)
+    sampler = ScanSampler(projs, hw, torch.Generator(device=device).manual_seed(1234 + rank))      # each rank draws its own shard
+    log(f"scan resident: {raygen.n_projections} projections, {min(v.numel() for v in sampler.valid)}.."
+        f"{max(v.numel() for v in sampler.valid)} valid pixels each")
 
-    torch.manual_seed(args.seed)                                       # identical initial weights on every rank
-    enc = HashEncoder(3, CHEST["num_levels"], CHEST["level_dim"], CHEST["base_resolution"], CHEST["log2_hashmap_size"])
-    net = DensityNetwork(enc, bound=CHEST["bound"], num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
-                         last_activation="sigmoid").to(device)
-    tdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
-    engine = NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"], table_dtype=tdt, seed=args.seed,
-                       process_group=pg, n_streams=args.streams, chunk_rays=args.chunk_rays)
+    def make_engine(precision, group):
+        torch.manual_seed(args.seed)                                   # identical initial weights on every rank
+        enc = HashEncoder(3, CHEST["num_levels"], CHEST["level_dim"], CHEST["base_resolution"], CHEST["log2_hashmap_size"])
+        net = DensityNetwork(enc, bound=CHEST["bound"], num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
+                             last_activation="sigmoid").to(device)
+        tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+        buckets = None
+        if args.buckets and group is not None:
+            buckets = [tuple(int(v) for v in b.split("-")) for b in args.buckets.split(",")]
+        return NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"], table_dtype=tdt, seed=args.seed,
+                         process_group=group, n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
+                         scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
+                         cfg_flags=_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0, bucket_levels=buckets)
 
-    # ---- per-step inputs, resident in HBM before the clock starts ------------------------------------------------
+    engine = make_engine(args.precision, pg)
+    allreduce_bytes = engine.grad_flat.numel() * 4
+    dp_buckets = None if engine._dp is None else [list(b) for b in engine._dp["levels"]]
     n = args.rays
     total_steps = args.warmup + args.steps
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)      # each rank draws its own ray shard
-    n_pix = raygen.n_projections * raygen.pixels_per_projection
-    pixels = torch.randint(0, n_pix, (total_steps, n), device=device, generator=gen)
-    targets = torch.empty(total_steps, n, device=device)
     rays = torch.empty(n, 8, device=device)
-    for i in range(total_steps):
-        raygen.rays_for_pixels(pixels[i], out=rays)
-        for j in range(0, n, 1 << 16):
-            targets[i, j:j + (1 << 16)] = phantom.line_integrals(rays[j:j + (1 << 16)], table)
     weight = torch.full((n,), 1.0 / (n * world), device=device)       # global mean over all ranks' rays
 
-    def step(i):
-        raygen.rays_for_pixels(pixels[i], out=rays)                   # G3: on-the-fly cone-beam ray generation
-        return engine.train_step(rays, targets[i], weight, ray_base=(i * world + rank) * n)
+    def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
+        pixels, target = sampler.draw(i, n_rays)                      # G6: valid-pixel sampling + target gather, on the device
+        raygen.rays_for_pixels(pixels, out=ray_buf)                   # G3: on-the-fly cone-beam ray generation
+        return (eng or engine).train_step(ray_buf, target, w, ray_base=(i * world + rank) * n_rays)
 
     def barrier():
         torch.cuda.synchronize()
@@ -171,11 +246,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-    log(f"inputs resident: {total_steps} x {n} rays; starting {args.warmup} warm-up steps")
+    log(f"starting {args.warmup} warm-up steps of {n} rays")
     for i in range(args.warmup):
         step(i)
         if i == 0:
@@ -183,6 +254,7 @@ def main():
             log("first step done")
     barrier()
     log(f"timing {args.steps} steps")
+    engine.comm_timing(True)
     _abi.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
@@ -191,28 +263,46 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _abi.profile_collect()
     _abi.profile_enable(False)
+    comm = engine.comm_report()
+    engine.comm_timing(False)
     log(f"timed region {elapsed:.3f} s")
     final_loss = float(loss.item())
     overflow = engine.scatter_overflow(n)
 
-    allreduce_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-        try:        # informational: cost of the one collective of a step (table + MLP gradients + loss), outside the timed region
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            engine.grad_flat.zero_()
-            torch.distributed.all_reduce(engine.grad_flat)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(5):
-                torch.distributed.all_reduce(engine.grad_flat)
-            e1.record()
-            torch.cuda.synchronize()
-            allreduce_ms = e0.elapsed_time(e1) / 5
-        except Exception as exc:                                       # never let the probe break the benchmark line
-            log(f"all-reduce probe skipped: {exc}")
+
+    def timed(fn, steps, warm):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(warm, warm + steps):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+
+    sub_records = None
+    if rank == 0 and world == 1 and args.sub_records and not args.force_dp:
+        log("sub-records: the YAML's 1024-ray step, the fp32 parity mode")
+        # (a) the YAML's own step: 1 024 rays of ONE projection, the reference's chunk-sum loss (train.py:69,127)
+        m = CHEST["yaml_rays"]
+        r1 = torch.empty(m, 8, device=device)
+        w1 = chunk_mean_weights(torch.ones(m, dtype=torch.bool, device=device), 200, "chunk_sum")
+        dt = timed(lambda i: step(i, engine, m, r1, w1), 200, 20)
+        sub_records = {"yaml_step_1024_rays": {"rays_per_step": m, "precision": args.precision, "ms_per_step": round(dt * 1e3, 4),
+                                               "rays_per_s": m / dt, "loss": "chunk_sum (sum of 200-ray chunk means)"}}
+        # (b) the reference's arithmetic: fp32 table, fp32 MFMA (bit-for-bit an fmaf chain), fp32 scatter records
+        if args.precision == "bf16":
+            e32 = make_engine("fp32", None)
+            m = 16384
+            r2, w2 = torch.empty(m, 8, device=device), torch.full((m,), 1.0 / m, device=device)
+            dt = timed(lambda i: step(i, e32, m, r2, w2), 10, 3)
+            sub_records["fp32_parity_mode_16384_rays"] = {"rays_per_step": m, "precision": "fp32", "ms_per_step": round(dt * 1e3, 4),
+                                                           "rays_per_s": m / dt}
+            del e32
 
     if rank == 0:
         rays_total = world * n * args.steps
@@ -227,6 +317,22 @@ def main():
         ms_per_step = {g: v for g, v in ms_per_step.items() if v > 0}
         mfma_peak = 2500.0 if args.precision == "bf16" else 157.3      # TFLOP/s dense, MI355X_MICROARCH.md
 
+        # HBM bytes by PMC counters come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); they are printed only
+        # while the kernel sources are the ones those passes ran on
+        traffic_table, traffic_note = {}, "profiles/pmc_traffic.json absent"
+        tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            doc = json.load(open(tf))
+            if doc.get("csrc_fingerprint") != source_fingerprint():
+                traffic_note = (f"stale: the PMC passes ran on kernel sources {doc.get('csrc_fingerprint')}, this build is "
+                                f"{source_fingerprint()} -- rerun tools/collect_profiles.sh + tools/install_profiles.py")
+            elif n != 65536 or world != 1:
+                traffic_note = "the PMC passes were taken at 65536 rays/step on one GPU"
+            else:
+                traffic_table = doc.get(args.precision, {})
+                traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {doc.get('collected_at_commit')}, "
+                                f"kernel sources {doc.get('csrc_fingerprint')}")
+
         def roof(group):
             t = ms_per_step[group] * 1e-3
             members = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in kernels.items()
@@ -236,12 +342,9 @@ def main():
             if group in ("hash_forward", "hash_backward"):
                 bytes_pp = algorithmic_bytes_per_point("encode_kernel" if group == "hash_forward" else "hash_backward_kernel", *sizes)
                 achieved = bytes_pp * points_per_launch / t / 1e9
-                traffic = None
-                tf = os.path.join(REPO, "profiles", "pmc_traffic.json")      # filled in from rocprofv3 --pmc passes
-                if os.path.exists(tf):
-                    traffic = json.load(open(tf)).get(args.precision, {}).get(group)
                 base.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_point": bytes_pp})
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_table.get(group),
+                             "algorithmic_bytes_per_point": bytes_pp})
             else:
                 flops_pp = {"mlp_forward": 8256, "mlp_backward": 3 * 8256}[group]
                 achieved = flops_pp * points_per_launch / t / 1e12
@@ -250,7 +353,7 @@ def main():
             return base
 
         dominant = max((g for g in ms_per_step if g != "adam"), key=lambda g: ms_per_step[g])
-        roofline = roof(dominant)
+        kernel_ms = sum(v["total_ms"] for v in kernels.values()) / args.steps
         out = {
             "metric": "train rays/sec, chest 256^3 / 50 proj", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -258,21 +361,33 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"chest_50.yaml: 256^3 volume, 50 cone-beam projections 512x512, hash L=16 T=2^19 C=2 "
                                    f"({args.precision} table), S=192, MLP 32-32-32-(64)-32-1, Adam; "
-                                   f"{n} rays/step/GPU (reference n_rays=1024), perturb=True",
+                                   f"{n} rays/step/GPU (reference n_rays=1024) = {min(n, RAYS_PER_PROJECTION)} distinct valid pixels from "
+                                   f"each of {max(1, n // RAYS_PER_PROJECTION)} projections, drawn on the device inside the step; perturb=True",
                        "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "parallelism": f"dp{world}"},
             "final_loss": final_loss, "scatter_overflow_last_step": overflow,
-            "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 4),
-            "allreduce_bytes": engine.grad_flat.numel() * 4,
-            "roofline": roofline,
+            "scatter_overflow_fraction": overflow / (points_per_launch * 128.0),
+            "library_kernels_ms_per_step": round(kernel_ms, 4),
+            "sampling_and_gaps_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 4),
+            "allreduce_ms_per_step": None, "allreduce_exposed_ms_per_step": None, "allreduce_buckets": dp_buckets,
+            "allreduce_bytes": allreduce_bytes,
+            "roofline": roof(dominant),
             "roofline_hash_forward": roof("hash_forward"),
             "roofline_all": {g: roof(g) for g in ms_per_step if g != "adam"},
+            "traffic_source": traffic_note,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernels.items())},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if comm is not None:
+            # in flight: the collectives on the side stream, measured by events inside the timed steps.  exposed: what the main
+            # stream waited after its own compute = tail (end of compute -> last Adam launched) minus the Adam kernels themselves
+            out["allreduce_ms_per_step"] = round(comm["allreduce_ms_per_step"], 4)
+            out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - ms_per_step.get("adam", 0.0)), 4)
+        if sub_records is not None:
+            out["sub_records"] = sub_records
+        if world == 1 and args.cpu_seconds > 0 and not args.force_dp:
             log("cpu_baseline leg (oracle, host cores)")
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 1024, args.seed)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

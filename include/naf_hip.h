@@ -14,7 +14,9 @@
  *     reference uses, hashencoder.cu:306,336);
  *   - every function returns NAF_OK (0) or a negative naf_status; naf_last_error() returns a
  *     thread-local human readable message for the last failure on the calling thread;
- *   - launches are asynchronous; no function synchronises or allocates device memory.
+ *   - launches are asynchronous; no function synchronises or allocates device memory;
+ *   - the library keeps NO mutable process-wide state besides the opt-in profiler (naf_profile_*): everything a call
+ *     depends on is in its arguments, so it is re-entrant across threads, streams and devices.
  */
 #ifndef NAF_HIP_H
 #define NAF_HIP_H
@@ -59,7 +61,15 @@ int naf_profile_collect(char *buf, size_t buflen);
  *   outputs     dtype, layout `out_layout`
  *   dy_dx       dtype [B, L, D, C]  written iff calc_grad_inputs != 0 (may be NULL otherwise)
  * D in {2,3}, C in {1,2,4,8} else NAF_ERR_UNSUPPORTED.
+ * calc_grad_inputs: NAF_GRAD_INPUTS_NONE, NAF_GRAD_INPUTS_EXACT (d feature / d x for x in [0,1], including the level
+ * scale 2^l*H-1 that the chain rule needs), or NAF_GRAD_INPUTS_REFERENCE (what hashencoder.cu:153-197 stores: the scale
+ * factor is commented out there, :164-165, and the loop picks the interpolated dimensions with `nd > gd`, :170, so for
+ * gd < D-1 one coordinate is never set -- the reference reads an uninitialised register there; this mode uses the base
+ * corner for it, the only defined reading).
  */
+#define NAF_GRAD_INPUTS_NONE 0
+#define NAF_GRAD_INPUTS_EXACT 1
+#define NAF_GRAD_INPUTS_REFERENCE 2
 int naf_hash_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H, int calc_grad_inputs,
                             void *dy_dx, int dtype, int out_layout, void *stream);
@@ -125,12 +135,17 @@ typedef struct naf_render_cfg {
     uint64_t seed;           /* jitter seed when t_rand == NULL                                   */
     uint32_t ray_index_base; /* global index of ray 0 of this call (jitter stream is per global ray) */
     uint32_t log2_hashmap_size; /* hashgrid.py:81 (sizes the binned gradient scatter; 0 = unknown -> plain atomics) */
+    int32_t scatter_mode;    /* how naf_render_backward / _train scatter the table gradient (NAF_SCATTER_*); part of the
+                                cfg because the workspace layout depends on it                                      */
+    uint32_t flags;          /* NAF_CFG_* bits                                                                     */
 } naf_render_cfg;
 
-/* How naf_render_backward / naf_render_train scatter the table gradient: 0 = auto (binned two-pass scatter from
- * 2^13 points per call, plain fp32 atomics below), 1 = always atomics (the reference's scheme, hashencoder.cu:257-269),
- * 2 = always binned.  Process-wide; call before naf_render_workspace_bytes (the workspace size depends on it). */
-int naf_set_scatter_mode(int mode);
+#define NAF_SCATTER_AUTO 0   /* binned two-pass scatter from 2^13 points per call, plain fp32 atomics below          */
+#define NAF_SCATTER_ATOMIC 1 /* always fp32 atomics: the reference's scheme (hashencoder.cu:257-269)                 */
+#define NAF_SCATTER_BINNED 2 /* always the binned scatter                                                            */
+
+#define NAF_CFG_PER_LEVEL_LAUNCHES 1u /* diagnostics: one launch per level instead of level-major grids, so that
+                                         naf_profile_collect() reports per-level times (changes the workspace size) */
 
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */
@@ -144,6 +159,14 @@ size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points);
 int naf_render_forward(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
                        const float *mlp, float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
                        void *stream);
+
+/* Forward with the per-sample quantities the coarse -> fine pass consumes (render.py:113-126, 203-211):
+ *   sigma          f32 [n_rays, S]  network output at every sample (NULL: not wanted)
+ *   optical_depth  f32 [n_rays, S]  running line integral tau[r,s] = sum_{s' <= s} sigma[r,s'] * dist[r,s'] -- an inclusive
+ *                                   wave prefix sum over the samples of a ray; tau[r,S-1] == acc[r] (NULL: not wanted) */
+int naf_render_forward_samples(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
+                               const float *mlp, float *acc, float *sigma, float *optical_depth, uint32_t n_rays,
+                               const naf_render_cfg *cfg, void *workspace, void *stream);
 
 /* Backward of naf_render_forward for an arbitrary upstream gradient grad_acc[r] = dLoss/dacc[r]
  * (what autograd hands to the renderer): grad_embeddings (+=), grad_mlp (+=).
@@ -163,6 +186,25 @@ int naf_render_train(const float *rays, const float *t_rand, const float *target
                      const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                      float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                      const naf_render_cfg *cfg, void *workspace, void *stream);
+
+/* The same step for data-parallel training (one process per GPU): the levels of the table are scattered in
+ * the order of `buckets`, and each bucket's event is recorded on `stream` as soon as its rows of grad_embeddings are
+ * final, so the caller can all-reduce that slice (RCCL, on another stream that waits for the event) while the next
+ * bucket is still being binned and reduced.  `mlp_ready` is recorded once grad_mlp and loss_out are final, which is
+ * before the table scatter starts.  Events are hipEvent_t handles owned by the caller; NULL entries are skipped.
+ * The buckets must be disjoint level ranges that cover [0, L).  Numerically identical to naf_render_train. */
+#define NAF_MAX_GRAD_BUCKETS 16
+typedef struct naf_grad_buckets {
+    uint32_t n_buckets;
+    uint32_t level_begin[NAF_MAX_GRAD_BUCKETS];
+    uint32_t level_end[NAF_MAX_GRAD_BUCKETS];
+    void *ready[NAF_MAX_GRAD_BUCKETS];
+    void *mlp_ready;
+} naf_grad_buckets;
+int naf_render_train_bucketed(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                              const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                              float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                              const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream);
 
 /* Field query sigma(x) for a point list (volume query, train.py:246-250): pts f32 [B,3] in [-bound,bound]. */
 int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,

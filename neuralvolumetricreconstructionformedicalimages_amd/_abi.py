@@ -16,6 +16,9 @@ from . import build as _build
 F32, F16, BF16 = 0, 1, 2
 LAYOUT_LBC, LAYOUT_BLC = 0, 1
 MLP_PARAMS = 4225
+SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED = 0, 1, 2
+CFG_PER_LEVEL_LAUNCHES = 1
+GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 _lib = None
@@ -28,6 +31,19 @@ class RenderCfg(ctypes.Structure):
         ("L", ctypes.c_uint32), ("C", ctypes.c_uint32), ("H", ctypes.c_uint32),
         ("table_dtype", ctypes.c_int32), ("mlp_precision", ctypes.c_int32), ("last_activation", ctypes.c_int32),
         ("seed", ctypes.c_uint64), ("ray_index_base", ctypes.c_uint32), ("log2_hashmap_size", ctypes.c_uint32),
+        ("scatter_mode", ctypes.c_int32), ("flags", ctypes.c_uint32),
+    ]
+
+
+MAX_GRAD_BUCKETS = 16
+
+
+class GradBuckets(ctypes.Structure):
+    """struct naf_grad_buckets (include/naf_hip.h): level ranges + the hipEvent_t recorded when each is final."""
+    _fields_ = [
+        ("n_buckets", ctypes.c_uint32), ("level_begin", ctypes.c_uint32 * MAX_GRAD_BUCKETS),
+        ("level_end", ctypes.c_uint32 * MAX_GRAD_BUCKETS), ("ready", ctypes.c_void_p * MAX_GRAD_BUCKETS),
+        ("mlp_ready", ctypes.c_void_p),
     ]
 
 
@@ -44,12 +60,14 @@ SIGNATURES = {
     "naf_generate_rays": (_i32, [_vp, _vp, ctypes.c_int64, _vp, _u64, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "naf_integrate_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "naf_integrate_backward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
-    "naf_set_scatter_mode": (_i32, [_i32]),
     "naf_scatter_overflow_count": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32)]),
     "naf_render_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
     "naf_render_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_render_forward_samples": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _i32, _vp]),
     "naf_render_train": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_render_train_bucketed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
+                                         ctypes.POINTER(GradBuckets), _vp]),
     "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _u64, _f32, _f32, _f32, _f32, _u32, _f32, _i32, _vp]),
     "naf_normalize_inputs": (_i32, [_vp, _u64, _f32, _vp, _vp, _vp]),

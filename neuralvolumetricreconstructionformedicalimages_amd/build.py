@@ -35,6 +35,17 @@ def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "naf_hip.h")]
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources and the ABI header: names what a measurement (profiles/pmc_traffic.json) was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_deps(), key=os.path.basename):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True

@@ -30,10 +30,10 @@ input_backward_kernel(const typename T::store_t *__restrict__ grad, const typena
 
 template <typename T, uint32_t D, uint32_t C>
 static int launch_forward(const float *inputs, const void *emb, const int32_t *offsets, void *out, uint32_t B, uint32_t L,
-                          uint32_t H, bool blc, void *dy_dx, hipStream_t s) {
+                          uint32_t H, bool blc, void *dy_dx, int jac_mode, hipStream_t s) {
     using S = typename T::store_t;
     { ProfScope prof_("hash_forward_kernel", s); hipLaunchKernelGGL((hash_forward_kernel<T, D, C, SrcUnit<D>>), dim3(hash_grid_x(B), L), dim3(256), 0, s,
-                       SrcUnit<D>{inputs}, (const S *)emb, offsets, (S *)out, B, L, H, blc, (S *)dy_dx); }
+                       SrcUnit<D>{inputs}, (const S *)emb, offsets, (S *)out, B, L, H, blc, (S *)dy_dx, jac_mode); }
     return check_launch("hash_forward_kernel");
 }
 
@@ -78,6 +78,8 @@ extern "C" int naf_hash_encode_forward(const float *inputs, const void *embeddin
                                        void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H,
                                        int calc_grad_inputs, void *dy_dx, int dtype, int out_layout, void *stream) {
     if (!inputs || !embeddings || !offsets || !outputs) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: null pointer");
+    if (calc_grad_inputs < NAF_GRAD_INPUTS_NONE || calc_grad_inputs > NAF_GRAD_INPUTS_REFERENCE)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: calc_grad_inputs must be NAF_GRAD_INPUTS_NONE, _EXACT or _REFERENCE");
     if (calc_grad_inputs && !dy_dx) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: calc_grad_inputs without dy_dx");
     if (L == 0 || L > 65535u) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: L must be in [1, 65535]");
     if (int rc = check_dims(D, C)) return rc;
@@ -86,9 +88,9 @@ extern "C" int naf_hash_encode_forward(const float *inputs, const void *embeddin
     void *jac = calc_grad_inputs ? dy_dx : nullptr;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case NAF_F32: NAF_DISPATCH_DC(F32, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, s); break;
-        case NAF_F16: NAF_DISPATCH_DC(F16, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, s); break;
-        case NAF_BF16: NAF_DISPATCH_DC(BF16, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, s); break;
+        case NAF_F32: NAF_DISPATCH_DC(F32, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, calc_grad_inputs, s); break;
+        case NAF_F16: NAF_DISPATCH_DC(F16, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, calc_grad_inputs, s); break;
+        case NAF_BF16: NAF_DISPATCH_DC(BF16, launch_forward, inputs, embeddings, offsets, outputs, B, L, H, blc, jac, calc_grad_inputs, s); break;
         default: break;
     }
     return fail(NAF_ERR_UNSUPPORTED, "hash_encode_forward: dtype must be NAF_F32, NAF_F16 or NAF_BF16");

@@ -25,6 +25,7 @@ namespace naf {
 // (a) caller-supplied coordinates already in [0,1]  (reference kernel contract, hashencoder.cu:383)
 template <uint32_t D>
 struct SrcUnit {
+    static constexpr bool kInRange = false;     // the reference kernel stays in bounds for any input (index % hashmap_size)
     const float *__restrict__ x;
     __device__ __forceinline__ void get(uint32_t b, float (&out)[D]) const {
 #pragma unroll
@@ -42,6 +43,7 @@ __device__ __forceinline__ float div_exact(float x, float d, float r) {
 
 // (b) raw coordinates in [-bound, bound]: the (x+size)/(2 size) of hashgrid.py:125 is applied in registers
 struct SrcRaw {
+    static constexpr bool kInRange = false;
     const float *__restrict__ pts;
     float bound;
     __device__ __forceinline__ void get(uint32_t b, float (&out)[3]) const {
@@ -54,6 +56,7 @@ struct SrcRaw {
 // (c) sample s of ray r (b = r*S + s): stratified depth, point on ray, clamp, normalise
 //     (render.py:87-105 + hashgrid.py:125) -- nothing [B,3]-sized ever touches HBM.
 struct SrcRays {
+    static constexpr bool kInRange = true;       // get() clamps to +-(bound - 1e-6) like render.py:104-105 (NaN -> the clamp value)
     const float *__restrict__ rays;    // [n_rays, 8]
     const float *__restrict__ t_rand;  // [n_rays, S] or nullptr
     uint32_t S;
@@ -112,13 +115,13 @@ template <typename T, uint32_t D, uint32_t C, typename Src>
 __global__ void __launch_bounds__(256)
 hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
                     typename T::store_t *__restrict__ outputs, uint32_t B, uint32_t L, uint32_t H, bool blc_layout,
-                    typename T::store_t *__restrict__ dy_dx, uint32_t level_base = 0) {
+                    typename T::store_t *__restrict__ dy_dx, int jac_mode, uint32_t level_base = 0) {
     using S = typename T::store_t;
     const uint32_t level = level_base + blockIdx.y;
     const LevelMeta m = make_level_meta<D>(offsets, level, H);
     const S *__restrict__ grid = table + (size_t)m.offset * C;
 
-    dispatch_mode(m.mode, [&](auto mode_tag) {
+    dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         float x[D];
@@ -146,7 +149,11 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
         S *out = blc_layout ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
         store_vec<T, C>(out, acc);
 
-        if (dy_dx != nullptr) {   // hashencoder.cu:153-197 ([B,L,D,C]; like the reference without the x scale factor)
+        if (dy_dx != nullptr) {   // hashencoder.cu:153-197, [B,L,D,C]
+            // jac_mode NAF_GRAD_INPUTS_EXACT: d out / d x[gd] = scale * sum over the corners of the other dimensions of
+            //   w * (right - left);  NAF_GRAD_INPUTS_REFERENCE: what the reference stores -- no scale (:164-165) and the
+            //   other dimensions picked with `nd > gd` (:170), which leaves one coordinate unset for gd < D-1 (base corner here).
+            const bool exact = jac_mode != 2;
             S *dst = dy_dx + ((size_t)b * L + level) * D * C;
 #pragma unroll
             for (uint32_t gd = 0; gd < D; ++gd) {
@@ -158,10 +165,16 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
                     float wc = 1.0f;
                     uint32_t pl[D];
 #pragma unroll
+                    for (uint32_t d = 0; d < D; ++d) pl[d] = pg[d];
+#pragma unroll
                     for (uint32_t nd = 0; nd < D - 1; ++nd) {
-                        const uint32_t d = nd >= gd ? nd + 1 : nd;
-                        if ((c >> nd) & 1u) { wc *= frac[d]; pl[d] = pg[d] + 1u; }
-                        else                { wc *= 1.0f - frac[d]; pl[d] = pg[d]; }
+                        const uint32_t d = exact ? (nd >= gd ? nd + 1 : nd) : (nd > gd ? nd + 1 : nd);
+                        // (a select over compile-time candidates: d is one of nd, nd + 1)
+                        const float f = d == nd ? frac[nd] : frac[nd + 1];
+                        const bool up = (c >> nd) & 1u;
+                        wc *= up ? f : 1.0f - f;
+                        if (d == nd) pl[nd] = pg[nd] + (up ? 1u : 0u);
+                        else pl[nd + 1] = pg[nd + 1] + (up ? 1u : 0u);
                     }
                     float lo[C], hi[C];
                     pl[gd] = pg[gd];
@@ -170,6 +183,10 @@ hash_forward_kernel(Src src, const typename T::store_t *__restrict__ table, cons
                     load_vec<T, C>(grid + (size_t)grid_row<MODE, D>(m, pl) * C, hi);
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) g[ch] = __fmaf_rn(wc, hi[ch] - lo[ch], g[ch]);
+                }
+                if (exact) {
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) g[ch] *= m.scale;
                 }
                 store_vec<T, C>(dst + gd * C, g);
             }
@@ -190,7 +207,7 @@ hash_backward_kernel(Src src, const typename T::store_t *__restrict__ grad, cons
     const LevelMeta m = make_level_meta<D>(offsets, level, H);
     float *__restrict__ gg = grad_table + (size_t)m.offset * C;
 
-    dispatch_mode(m.mode, [&](auto mode_tag) {
+    dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         float x[D];
@@ -212,12 +229,8 @@ hash_backward_kernel(Src src, const typename T::store_t *__restrict__ grad, cons
     });
 }
 
-// NAF_PROFILE_LEVELS=1 splits the level-major launches into one launch per level so that
+// naf_render_cfg.flags & NAF_CFG_PER_LEVEL_LAUNCHES splits the level-major launches into one launch per level so that
 // naf_profile_collect() reports a per-level time (diagnostics only).
-static inline bool profile_levels() {
-    static const bool on = [] { const char *e = std::getenv("NAF_PROFILE_LEVELS"); return e && e[0] == '1'; }();
-    return on;
-}
 static inline const char *level_name(const char *const (&names)[32], uint32_t l) { return names[l < 32 ? l : 31]; }
 #define NAF_LEVEL_NAMES(P) { P "00", P "01", P "02", P "03", P "04", P "05", P "06", P "07", P "08", P "09", P "10", P "11", \
                              P "12", P "13", P "14", P "15", P "16", P "17", P "18", P "19", P "20", P "21", P "22", P "23", \

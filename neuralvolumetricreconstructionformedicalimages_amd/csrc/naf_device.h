@@ -20,8 +20,12 @@ enum IndexMode : uint32_t {
     kDenseMask = 1,   // dense (possibly uint32-wrapped) strides, T is a power of two -> mask
     kDenseMod = 2,    // dense, general T -> real modulo
     kHashMask = 3,    // xor-prime hash, T is a power of two -> mask
-    kHashMod = 4      // xor-prime hash, general T
+    kHashMod = 4,     // xor-prime hash, general T
+    kDenseGuard = 5   // kDenseNoMod for coordinates nobody has range-checked: `idx % T` (hashencoder.cu:74) is the identity
+                      // for x in [0,1] only, so the modulo is kept behind a compare (one v_cmp per corner, never taken in range)
 };
+
+__host__ __device__ constexpr bool is_hash_mode(uint32_t mode) { return mode == kHashMask || mode == kHashMod; }
 
 struct LevelMeta {
     uint32_t offset;  // first row of the level in the table
@@ -75,7 +79,7 @@ __device__ __forceinline__ LevelMeta make_level_meta(const int32_t *__restrict__
 template <uint32_t MODE, uint32_t D>
 __device__ __forceinline__ uint32_t grid_row(const LevelMeta &m, const uint32_t (&p)[D]) {
     uint32_t idx;
-    if constexpr (MODE >= kHashMask) {
+    if constexpr (is_hash_mode(MODE)) {
         idx = p[0];                         // prime 1
         idx ^= p[1] * kPrime1;
         if constexpr (D > 2) idx ^= p[2] * kPrime2;
@@ -84,16 +88,22 @@ __device__ __forceinline__ uint32_t grid_row(const LevelMeta &m, const uint32_t 
         if constexpr (D > 2) idx += p[2] * m.stride2;
     }
     if constexpr (MODE == kDenseMask || MODE == kHashMask) idx &= (m.size - 1u);
+    else if constexpr (MODE == kDenseGuard) { if (idx >= m.size) idx %= m.size; }
     else if constexpr (MODE != kDenseNoMod) idx %= m.size;
     return idx;
 }
 
 // Runs `body(std::integral_constant<uint32_t, MODE>{})` for the (wave-uniform) regime of the level: one scalar
 // branch per kernel instead of one per corner, and straight-line gather code inside.
-template <typename Body>
+// kInRange = the point source guarantees coordinates in [0,1] (SrcRays clamps like render.py:104-105); every other source
+// (caller-supplied coordinates) gets kDenseGuard instead of kDenseNoMod, i.e. the reference's in-bounds behaviour for ANY input.
+template <bool kInRange, typename Body>
 __device__ __forceinline__ void dispatch_mode(uint32_t mode, Body &&body) {
     switch (mode) {
-        case kDenseNoMod: body(std::integral_constant<uint32_t, kDenseNoMod>{}); break;
+        case kDenseNoMod:
+            if constexpr (kInRange) body(std::integral_constant<uint32_t, kDenseNoMod>{});
+            else body(std::integral_constant<uint32_t, kDenseGuard>{});
+            break;
         case kDenseMask:  body(std::integral_constant<uint32_t, kDenseMask>{}); break;
         case kDenseMod:   body(std::integral_constant<uint32_t, kDenseMod>{}); break;
         case kHashMask:   body(std::integral_constant<uint32_t, kHashMask>{}); break;
@@ -102,14 +112,17 @@ __device__ __forceinline__ void dispatch_mode(uint32_t mode, Body &&body) {
 }
 
 // hashencoder.cu:106-111.  nvcc contracts x*scale+0.5 into an FMA; we ask for it explicitly.
+// The reference subtracts the CONVERTED cell index, pos -= (float)pos_grid, and its float -> uint32 conversion saturates
+// (negative and NaN -> 0, >= 2^32 -> 2^32-1, exactly what v_cvt_u32_f32 does).  For 0 <= pos < 2^32 that is pos - floor(pos);
+// outside (coordinates nobody range-checked, or levels whose resolution exceeds uint32) it is not, and the extra
+// conversion per dimension keeps every kernel bit-identical to the reference there too.
 template <uint32_t D>
 __device__ __forceinline__ void locate(const float (&x)[D], float scale, float (&frac)[D], uint32_t (&pg)[D]) {
 #pragma unroll
     for (uint32_t d = 0; d < D; ++d) {
         const float pos = __fmaf_rn(x[d], scale, 0.5f);
-        const float fl = floorf(pos);
-        pg[d] = (uint32_t)fl;
-        frac[d] = pos - fl;
+        pg[d] = (uint32_t)floorf(pos);
+        frac[d] = pos - (float)pg[d];
     }
 }
 
@@ -135,7 +148,7 @@ __device__ __forceinline__ void cell_corners(const LevelMeta &m, const float (&f
 #pragma unroll
     for (uint32_t d = 0; d < D; ++d) {
         uint32_t k;
-        if constexpr (MODE >= kHashMask) k = d == 0 ? 1u : d == 1 ? kPrime1 : kPrime2;
+        if constexpr (is_hash_mode(MODE)) k = d == 0 ? 1u : d == 1 ? kPrime1 : kPrime2;
         else k = d == 0 ? 1u : d == 1 ? m.stride1 : m.stride2;
         term[d][0] = d == 0 ? pg[0] : pg[d] * k;
         term[d][1] = term[d][0] + k;
@@ -148,10 +161,11 @@ __device__ __forceinline__ void cell_corners(const LevelMeta &m, const float (&f
         for (uint32_t d = 0; d < D; ++d) {
             const uint32_t bit = (c >> d) & 1u;
             wc *= bit ? frac[d] : 1.0f - frac[d];
-            if constexpr (MODE >= kHashMask) idx ^= term[d][bit];
+            if constexpr (is_hash_mode(MODE)) idx ^= term[d][bit];
             else idx += term[d][bit];
         }
         if constexpr (MODE == kDenseMask || MODE == kHashMask) idx &= (m.size - 1u);
+        else if constexpr (MODE == kDenseGuard) { if (idx >= m.size) idx %= m.size; }
         else if constexpr (MODE != kDenseNoMod) idx %= m.size;
         w[c] = wc;
         row[c] = idx;
@@ -273,6 +287,16 @@ __device__ __forceinline__ void raw_unpack(const RawVec<T, C> &r, float (&v)[C])
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, i.e.
 // s_waitcnt vmcnt(0): every wave would sit out the round trip of the global stores it has just issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Value of lane (l - kShift) of the same 16-lane row, 0 for the first kShift lanes of a row: a DPP row_shr modifier on the
+// consuming VALU instruction, no LDS crossbar traffic.  Every lane of the wave must execute it (convergent).
+template <uint32_t kShift>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v) {
+    static_assert(kShift >= 1 && kShift <= 15, "row_shr:1..15");
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + kShift, 0xf, 0xf, true);
+}
+template <uint32_t kShift>
+__device__ __forceinline__ float dpp_row_shr(float v) { return __uint_as_float(dpp_row_shr<kShift>(__float_as_uint(v))); }
 
 // ---- counter-based jitter (used when the caller passes no t_rand) --------------------------------
 // Two rounds of the "lowbias32" integer finaliser over (seed, global ray index, sample); 24 bits -> [0,1).

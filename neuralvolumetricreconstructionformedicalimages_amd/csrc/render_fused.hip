@@ -117,12 +117,34 @@ __device__ __forceinline__ float sample_dist(const SrcRays &src, uint32_t r, uin
     return (src.depth(r, s + 1u, near, far) - src.depth(r, s, near, far)) * dnorm;
 }
 
+// Per-sample outputs of the forward pass (what the fine pass consumes, render.py:113-126,203-211): the network output
+// sigma[r,s] and the RUNNING optical depth tau[r,s] = sum_{s' <= s} sigma * dist.  The W samples of a tile sit in W
+// consecutive lanes; the running sum is an inclusive wave prefix sum over them (log2 W shuffle steps) plus the carry
+// of the ray's earlier tiles.  Every lane of the wave takes part in the shuffles; `writer` lanes store.  Returns the new carry.
+template <uint32_t W>
+__device__ __forceinline__ float emit_samples(float term, float sigma, float carry, bool writer, uint32_t pos,
+                                              float *__restrict__ sigma_out, float *__restrict__ depth_out, size_t idx) {
+    float scan = term;
+#pragma unroll
+    for (uint32_t d = 1; d < W; d <<= 1) {
+        const float up = __shfl_up(scan, d, W);
+        if (pos >= d) scan += up;
+    }
+    scan += carry;
+    if (writer) {
+        if (sigma_out != nullptr) sigma_out[idx] = sigma;
+        if (depth_out != nullptr) depth_out[idx] = scan;
+    }
+    return __shfl(scan, W - 1u, W);          // the tile's last sample carries the total so far (lanes past S add 0)
+}
+
 // ---- 2: MLP forward + line integral ----------------------------------------------------------------------
 // kRays: one wave per ray, acc[r] = sum_s sigma*dist.   !kRays: plain point list, out[p] = sigma(p).
 template <typename P, uint32_t C, bool kRays>
 __global__ void __launch_bounds__(256, 3)
 mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
-                   float *__restrict__ out, uint32_t n_items, uint32_t B, int act) {
+                   float *__restrict__ out, float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items,
+                   uint32_t B, int act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MlpShared<P>::build(smem, mlp, 4);
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -141,7 +163,7 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
             const float near = ray[6], far = ray[7];
             const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
             if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
-            float part = 0.0f;
+            float part = 0.0f, carry = 0.0f;
             for (uint32_t k = 0; k < tiles; ++k) {
                 const uint32_t s = 32u * k + n;
                 const bool valid = s < S;
@@ -155,8 +177,11 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
                 unpack_feat_raw<typename P::feat_t, C>(now, x0);
                 const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
                 const float sigma = last_act(act, z4);
-                if (valid && h == 0)
-                    part += sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                const float term = !valid ? 0.0f
+                                 : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                if (sigma_out != nullptr || depth_out != nullptr)          // per-sample outputs (wave-uniform test)
+                    carry = emit_samples<32>(term, sigma, carry, valid && h == 0, n, sigma_out, depth_out, (size_t)r * S + s);
+                if (h == 0) part += term;
             }
             part = wave_sum32(part);
             if (lane == 0) out[r] = part;
@@ -178,7 +203,7 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
 template <bool kRays>
 __global__ void __launch_bounds__(256, 4)
 mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src, float *__restrict__ out,
-                     uint32_t n_items, uint32_t B, int act) {
+                     float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items, uint32_t B, int act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Mlp16Shared::build(smem, mlp, 4);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
@@ -195,7 +220,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             const float near = ray[6], far = ray[7];
             const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
             if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
-            float part = 0.0f;
+            float part = 0.0f, carry = 0.0f;
             for (uint32_t k = 0; k < tiles; ++k) {
                 const uint32_t s = 16u * k + c;
                 const bool valid = s < S;
@@ -208,8 +233,11 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
                 }
                 const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(now), a);
                 const float sigma = last_act(act, z4);
-                if (valid && g == 0u)
-                    part += sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                const float term = !valid ? 0.0f
+                                 : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                if (sigma_out != nullptr || depth_out != nullptr)          // per-sample outputs (wave-uniform test)
+                    carry = emit_samples<16>(term, sigma, carry, valid && g == 0u, c, sigma_out, depth_out, (size_t)r * S + s);
+                if (g == 0u) part += term;
             }
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);     // the 16 points of lane group 0
@@ -263,7 +291,8 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
     // weight-gradient accumulators: lane (c,h), register t  <->  dW[out = slot_row(t,h)][in = c]
     f32x16 dW0 = {0}, dW1 = {0}, dW2a = {0}, dW2b = {0};
     float db0 = 0.0f, db1 = 0.0f, db2 = 0.0f, db3 = 0.0f;
-    float dmax = 0.0f;                                       // max |feature gradient| (scale of the binned scatter)
+    uint32_t dmax = 0u;                                      // bit pattern of max |feature gradient| (scale of the binned scatter);
+                                                             // compared as integers so that Inf / NaN win and stay visible
     float dw3[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) dw3[t] = 0.0f;
@@ -355,7 +384,7 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
             if (valid) {
                 float o[16];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) { o[t] = dx0[t]; dmax = fmaxf(dmax, fabsf(o[t])); }
+                for (int t = 0; t < 16; ++t) { o[t] = dx0[t]; dmax = max(dmax, __float_as_uint(o[t]) & 0x7fffffffu); }
                 store_feat_slots<typename P::feat_t, C>(dfeat, B, p, h, o);
             }
         }
@@ -363,8 +392,8 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
 
     if (gmax_bits != nullptr) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-        if (lane == 0 && dmax > 0.0f) atomicMax(gmax_bits, __float_as_uint(dmax));      // positive floats order like uints
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+        if (lane == 0 && dmax != 0u) atomicMax(gmax_bits, dmax);                        // non-negative floats order like uints
     }
 
     // ---- fold the 4 waves of the workgroup into one slab (fixed order -> deterministic), then one store ------
@@ -472,7 +501,8 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         for (int q = 0; q < 4; ++q) dW2[o][q] = zero4;
     }
     float db[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};                 // per lane: output 16o + (lane & 15), its 4 points
-    float db3 = 0.0f, dmax = 0.0f;
+    float db3 = 0.0f;
+    uint32_t dmax = 0u;                                      // see mlp_backward_kernel
     f32x4v dw3lo = zero4, dw3hi = zero4;
 
     const uint32_t S = src.S, tiles = (S + 15u) / 16u;
@@ -581,7 +611,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             dxhi = mma16(Mlp16Shared::frag(wsh, kFW0T, 1, lane), gf, dxhi);
             if (valid) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dmax = fmaxf(dmax, fmaxf(fabsf(dxlo[j]), fabsf(dxhi[j])));
+                for (int j = 0; j < 4; ++j) dmax = max(dmax, max(__float_as_uint(dxlo[j]) & 0x7fffffffu, __float_as_uint(dxhi[j]) & 0x7fffffffu));
                 const uint4 o4 = __builtin_bit_cast(uint4, pack16(dxlo, dxhi));
                 uint32_t *df = reinterpret_cast<uint32_t *>(dfeat);
                 df[(size_t)(2u * g) * B + p] = o4.x;
@@ -594,8 +624,8 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
 
     if (gmax_bits != nullptr) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-        if (lane == 0 && dmax > 0.0f) atomicMax(gmax_bits, __float_as_uint(dmax));      // positive floats order like uints
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+        if (lane == 0 && dmax != 0u) atomicMax(gmax_bits, dmax);                        // non-negative floats order like uints
     }
 
     // ---- fold the 4 waves of the workgroup into one slab (wave order -> deterministic), then one store ---------------
@@ -687,11 +717,16 @@ mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float 
 // ---- host side ----------------------------------------------------------------------------------------------
 constexpr uint32_t kBackwardBlocks = 512;   // 2 workgroups of 4 waves per CU; also the number of dW slabs
 
-// 16-point-tile MLP kernels (bf16 mode, C = 2); NAF_MLP16=0 selects the 32-point kernels for comparison
-static inline bool use_mlp16() {
-    static const bool on = [] { const char *e = std::getenv("NAF_MLP16"); return !(e && e[0] == '0'); }();
-    return on;
+// Raise a kernel's dynamic-LDS limit.  The attribute is per device and the call is a cheap host-side table update, so it
+// is simply made before every launch of a kernel that may need more than the default: no cached flag to go stale when the
+// same process drives a second GPU or a second thread (the ABI takes a stream per call and keeps no state of its own).
+template <typename K>
+static int raise_lds_limit(K kernel, uint32_t bytes, const char *who) {
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(NAF_ERR_LAUNCH, who);
+    return NAF_OK;
 }
+static inline bool per_level_launches(const naf_render_cfg *cfg) { return (cfg->flags & NAF_CFG_PER_LEVEL_LAUNCHES) != 0u; }
 
 template <typename P>
 static uint32_t forward_lds_bytes() { return ((MlpShared<P>::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u; }
@@ -723,11 +758,9 @@ static size_t record_bytes(const naf_render_cfg *cfg) {
     return cfg->mlp_precision == NAF_F32 ? 4u * (1u + cfg->C) : 4u * (1u + (cfg->C + 1u) / 2u);
 }
 
-static int g_scatter_mode = 0;      // naf_set_scatter_mode: 0 auto, 1 always atomics, 2 always binned
-
 static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan *plan) {
-    if (g_scatter_mode == 1 || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
-    if (g_scatter_mode == 0 && n_points < kBinMinPoints) return false;
+    if (cfg->scatter_mode == NAF_SCATTER_ATOMIC || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
+    if (cfg->scatter_mode == NAF_SCATTER_AUTO && n_points < kBinMinPoints) return false;
     const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
@@ -747,7 +780,7 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
     const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
-    if (profile_levels()) plan->levels_per_pass = 1;
+    if (per_level_launches(cfg)) plan->levels_per_pass = 1;
     return true;
 }
 static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points) {
@@ -791,6 +824,8 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
+    if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
     return NAF_OK;
 }
@@ -807,7 +842,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     const uint32_t level = level_base + blockIdx.y;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
-    dispatch_mode(m.mode, [&](auto mode_tag) {
+    dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     // several points per thread and iteration: 32 independent gathers in flight per lane (measured on the chest step,
     // C = 2: 1 / 2 / 4 / 8 points -> 3.28 / 2.99 / 2.81 / 2.90 ms)
@@ -847,7 +882,7 @@ template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
     using FT = typename P::feat_t;
     constexpr uint32_t kPts = encode_points_per_thread(C);
-    if (profile_levels()) {
+    if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
         for (uint32_t l = 0; l < cfg->L; ++l) {
             ProfScope prof_(level_name(names, l), s);
@@ -872,14 +907,14 @@ static int dispatch_encode(const Src &src, const void *table, const int32_t *off
 
 template <typename P, uint32_t C, bool kRays>
 static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &src, float *out, uint32_t n_items, uint32_t B,
-                           const naf_render_cfg *cfg, hipStream_t s) {
+                           const naf_render_cfg *cfg, hipStream_t s, float *sigma_out = nullptr, float *depth_out = nullptr) {
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
-        if (use_mlp16()) {
+        {
             const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u;
             const uint64_t waves16 = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves16 + 3) / 4, 256u * 8u));
             { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL((mlp16_forward_kernel<kRays>), dim3(grid16), dim3(256), lds16, s,
-                               (const uint16_t *)feat, mlp, src, out, n_items, B, cfg->last_activation); }
+                               (const uint16_t *)feat, mlp, src, out, sigma_out, depth_out, n_items, B, cfg->last_activation); }
             return check_launch("mlp16_forward_kernel");
         }
     }
@@ -887,8 +922,8 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     const uint32_t lds = forward_lds_bytes<P>();
     const uint64_t waves_needed = kRays ? n_items : ((uint64_t)n_items + 31) / 32;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, 256u * 8u));
-    { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, n_items, B,
-                       cfg->last_activation); }
+    { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, sigma_out,
+                       depth_out, n_items, B, cfg->last_activation); }
     return check_launch("mlp_forward_kernel");
 }
 
@@ -897,7 +932,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
                             float *slabs, uint32_t *gmax_bits, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg,
                             hipStream_t s) {
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
-        if (use_mlp16()) {
+        {
             const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
             const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
             if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
@@ -911,12 +946,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     }
     auto kern = mlp_backward_kernel<P, C>;
     const uint32_t lds = backward_lds_bytes<P>();
-    static bool attr_set = false;       // raise the dynamic-LDS cap once per instantiation (fp32 images need > 64 KiB)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(NAF_ERR_LAUNCH, "mlp_backward_kernel: cannot raise dynamic LDS limit");
-        attr_set = true;
-    }
+    if (int rc = raise_lds_limit(kern, lds, "mlp_backward_kernel: cannot raise dynamic LDS limit")) return rc;      // fp32 images need > 64 KiB
     if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
@@ -928,7 +958,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
 
 template <typename P, uint32_t C, typename Rec, uint32_t NT>
 static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                                 const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+                                 const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
     using FT = typename P::feat_t;
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
     // position is evaluated once per point, and stores drain behind the next level: 3.85 -> 3.53 ms at 65 536 rays),
@@ -942,32 +972,21 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;
     const uint32_t bin_lds = 2u * NB * 4u + NB * plan.slot_cap * (uint32_t)sizeof(Rec);
-    // the dynamic-LDS cap of a kernel is raised whenever a plan needs more than any earlier one (per instantiation)
-    static uint32_t red_cap = 0, bin_cap = 0;
-    if (red_lds > red_cap) {
-        if (hipFuncSetAttribute((const void *)red, hipFuncAttributeMaxDynamicSharedMemorySize, (int)red_lds) != hipSuccess)
-            return fail(NAF_ERR_LAUNCH, "binned scatter: cannot raise dynamic LDS limit (reduce)");
-        red_cap = red_lds;
-    }
-    if (bin_lds > bin_cap) {
-        if (hipFuncSetAttribute((const void *)scatter_bin_kernel<FT, C, SrcRays, Rec, NT, kLvMany>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)scatter_bin_kernel<FT, C, SrcRays, Rec, NT, kLvFew>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds) != hipSuccess)
-            return fail(NAF_ERR_LAUNCH, "binned scatter: cannot raise dynamic LDS limit (bin)");
-        bin_cap = bin_lds;
-    }
-    if (hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
-    for (uint32_t l0 = 0; l0 < cfg->L; l0 += plan.levels_per_pass) {
-        const uint32_t nl = std::min(plan.levels_per_pass, cfg->L - l0);
+    if (int rc = raise_lds_limit(red, red_lds, "binned scatter: cannot raise dynamic LDS limit (reduce)")) return rc;
+    if (int rc = raise_lds_limit(bin, bin_lds, "binned scatter: cannot raise dynamic LDS limit (bin)")) return rc;
+    for (uint32_t l0 = lv_begin; l0 < lv_end; l0 += plan.levels_per_pass) {
+        const uint32_t nl = std::min(plan.levels_per_pass, lv_end - l0);
         static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
         static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
-        const bool per_level = profile_levels();
+        const bool per_level = per_level_launches(cfg);
         { ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
           hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(NT), bin_lds, s, src, (const typename FT::store_t *)dfeat,
                              offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan); }
         if (int rc = check_launch("scatter_bin_kernel")) return rc;
         { ProfScope prof_(per_level ? level_name(red_names, l0) : "scatter_reduce_kernel", s);
-          // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles
-          const uint32_t n_split = std::max(1u, std::min(16u, 1024u / (NB * nl)));
+          // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles.
+          // (A reducer workgroup owns a CU's LDS, so 256 run at a time: 512 or more unsplit ones already come in full rounds.)
+          const uint32_t n_split = NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl)));
           hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
                              grad_table, w.sums, w.gmax, cfg->H, l0, plan);
           if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
@@ -980,35 +999,52 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
 
 template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                              const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+                              const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
     if constexpr (sizeof(Rec) <= 8) {                            // tile size chosen by make_bin_plan
-        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
-        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
+        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
     } else {
-        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
     }
 }
 
+// Table-gradient scatter of the levels [lv_begin, lv_end).
 template <typename P, uint32_t C>
-static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                             const naf_render_cfg *cfg, const Workspace &w, hipStream_t s) {
+static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                                    const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, s);
-        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, s);
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
+        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
     }
-    if (profile_levels()) {
+    if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("hash_backward_kernel_L");
-        for (uint32_t l = 0; l < cfg->L; ++l) {
+        for (uint32_t l = lv_begin; l < lv_end; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), 1), dim3(256), 0, s, src,
                                (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false, l);
         }
         return check_launch("hash_backward_kernel");
     }
-    { ProfScope prof_("hash_backward_kernel", s); hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), cfg->L), dim3(256), 0, s, src,
-                       (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false, 0u); }
+    { ProfScope prof_("hash_backward_kernel", s); hipLaunchKernelGGL((hash_backward_kernel<FT, 3, C, SrcRays>), dim3(hash_grid_x(B), lv_end - lv_begin), dim3(256), 0, s, src,
+                       (const typename FT::store_t *)dfeat, offsets, grad_table, B, cfg->L, cfg->H, false, lv_begin); }
     return check_launch("hash_backward_kernel");
+}
+
+// All levels, in the order of `buckets` when given (data-parallel training: each bucket's event is recorded on the stream as
+// soon as its rows of the gradient table are final, so that the caller can start that bucket's all-reduce while the next
+// bucket is still being binned and reduced).
+template <typename P, uint32_t C>
+static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                             const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s) {
+    if (w.binned && hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
+    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s);
+    for (uint32_t b = 0; b < buckets->n_buckets; ++b) {
+        if (int rc = run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, buckets->level_begin[b], buckets->level_end[b], s)) return rc;
+        if (buckets->ready[b] != nullptr && hipEventRecord((hipEvent_t)buckets->ready[b], s) != hipSuccess)
+            return fail(NAF_ERR_LAUNCH, "render_train: cannot record a bucket event");
+    }
+    return NAF_OK;
 }
 
 static SrcRays make_src(const float *rays, const float *t_rand, const naf_render_cfg *cfg) {
@@ -1023,31 +1059,35 @@ static SrcRays make_src(const float *rays, const float *t_rand, const naf_render
 
 template <typename P, uint32_t C>
 static int render_forward_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, const float *mlp,
-                               float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+                               float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s,
+                               float *sigma_out = nullptr, float *depth_out = nullptr) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
     if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    return run_mlp_forward<P, C, true>(w.feat, mlp, src, acc, n_rays, B, cfg, s);
+    return run_mlp_forward<P, C, true>(w.feat, mlp, src, acc, n_rays, B, cfg, s, sigma_out, depth_out);
 }
 
 template <typename P, uint32_t C>
 static int render_backward_impl(const float *rays, const float *t_rand, const float *grad_acc, const void *emb, const int32_t *offsets,
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
-                                void *ws, int features_valid, hipStream_t s) {
+                                void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
     if (!features_valid)
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
     if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, n_rays, B, cfg, s)) return rc;
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, s);
+    // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
+    if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
+        return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s);
 }
 
 template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
-                             uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+                             uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
     const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
     {   // the partial sums live behind grad_acc in the workspace (carve reserves 256 bytes for them)
@@ -1058,7 +1098,7 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
         if (blocks > 1u && loss_out != nullptr) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, blocks, loss_out);
     }
     if (int rc = check_launch("loss_grad_kernel")) return rc;
-    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, s);
+    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s);
 }
 
 template <typename P, uint32_t C>
@@ -1093,12 +1133,6 @@ static int field_forward_impl(const float *pts, const void *emb, const int32_t *
 
 using namespace naf;
 
-extern "C" int naf_set_scatter_mode(int mode) {
-    if (mode < 0 || mode > 2) return fail(NAF_ERR_INVALID_ARGUMENT, "set_scatter_mode: mode must be 0 (auto), 1 (atomic) or 2 (binned)");
-    g_scatter_mode = mode;
-    return NAF_OK;
-}
-
 extern "C" int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host) {
     if (!cfg || !workspace || !count_host) return fail(NAF_ERR_INVALID_ARGUMENT, "scatter_overflow_count: null pointer");
     const Workspace w = carve(const_cast<void *>(workspace), cfg, n_points);
@@ -1129,6 +1163,18 @@ extern "C" int naf_render_forward(const float *rays, const float *t_rand, const 
     NAF_DISPATCH_PC(render_forward_impl, rays, t_rand, embeddings, offsets, mlp, acc, n_rays, cfg, workspace, (hipStream_t)stream);
 }
 
+extern "C" int naf_render_forward_samples(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
+                                          const float *mlp, float *acc, float *sigma, float *optical_depth, uint32_t n_rays,
+                                          const naf_render_cfg *cfg, void *workspace, void *stream) {
+    if (int rc = check_cfg(cfg, "render_forward_samples")) return rc;
+    if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    NAF_DISPATCH_PC(render_forward_impl, rays, t_rand, embeddings, offsets, mlp, acc, n_rays, cfg, workspace, (hipStream_t)stream, sigma,
+                    optical_depth);
+}
+
 extern "C" int naf_render_backward(const float *rays, const float *t_rand, const float *grad_acc, const void *embeddings,
                                    const int32_t *offsets, const float *mlp, float *grad_embeddings, float *grad_mlp,
                                    uint32_t n_rays, const naf_render_cfg *cfg, void *workspace, int features_valid, void *stream) {
@@ -1139,21 +1185,61 @@ extern "C" int naf_render_backward(const float *rays, const float *t_rand, const
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
     if (n_rays == 0) return NAF_OK;
     NAF_DISPATCH_PC(render_backward_impl, rays, t_rand, grad_acc, embeddings, offsets, mlp, grad_embeddings, grad_mlp, n_rays, cfg,
-                    workspace, features_valid, (hipStream_t)stream);
+                    workspace, features_valid, nullptr, (hipStream_t)stream);
+}
+
+static int check_buckets(const naf_grad_buckets *b, uint32_t L) {
+    if (b->n_buckets == 0 || b->n_buckets > NAF_MAX_GRAD_BUCKETS) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: n_buckets must be in [1, 16]");
+    uint32_t seen = 0;                                       // every level exactly once (L <= 32 on the fused path)
+    for (uint32_t i = 0; i < b->n_buckets; ++i) {
+        if (b->level_begin[i] >= b->level_end[i] || b->level_end[i] > L) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: empty or out-of-range bucket");
+        for (uint32_t l = b->level_begin[i]; l < b->level_end[i]; ++l) {
+            if (seen & (1u << l)) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: buckets overlap");
+            seen |= 1u << l;
+        }
+    }
+    if (seen != (L >= 32u ? 0xffffffffu : (1u << L) - 1u)) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: buckets do not cover all levels");
+    return NAF_OK;
+}
+
+static int render_train_entry(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                              const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                              float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                              const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream) {
+    if (int rc = check_cfg(cfg, "render_train")) return rc;
+    if (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (buckets != nullptr)
+        if (int rc = check_buckets(buckets, cfg->L)) return rc;
+    if (n_rays == 0) {                                       // an empty shard still has to signal its (zero) gradients as final
+        if (buckets != nullptr) {
+            if (buckets->mlp_ready && hipEventRecord((hipEvent_t)buckets->mlp_ready, (hipStream_t)stream) != hipSuccess) return fail(NAF_ERR_LAUNCH, "render_train: event");
+            for (uint32_t b = 0; b < buckets->n_buckets; ++b)
+                if (buckets->ready[b] && hipEventRecord((hipEvent_t)buckets->ready[b], (hipStream_t)stream) != hipSuccess) return fail(NAF_ERR_LAUNCH, "render_train: event");
+        }
+        return NAF_OK;
+    }
+    NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
                                 const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                                 float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                                 const naf_render_cfg *cfg, void *workspace, void *stream) {
-    if (int rc = check_cfg(cfg, "render_train")) return rc;
-    if (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace)
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: null pointer");
-    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: n_samples must be >= 2");
-    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
-    if (n_rays == 0) return NAF_OK;
-    NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, (hipStream_t)stream);
+    return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
+                              n_rays, cfg, workspace, nullptr, stream);
+}
+
+extern "C" int naf_render_train_bucketed(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                         const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                         float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                         const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream) {
+    if (!buckets) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: null buckets");
+    return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
+                              n_rays, cfg, workspace, buckets, stream);
 }
 
 extern "C" int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,

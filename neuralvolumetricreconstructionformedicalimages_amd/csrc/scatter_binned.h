@@ -73,15 +73,23 @@ struct BinPlan {
 };
 
 // Fixed-point scale of the reducer.  `gmax_bits` = bit pattern of max |feature gradient| of the step (written by the MLP
-// backward kernel); every contribution is w * g with 0 <= w <= 1, so |v| <= gmax < 2^(E+1) with E = exponent(gmax).
-// fixed = v * 2^(kFixHead - E - 1)  keeps |fixed| < 2^kFixHead and leaves 63 - kFixHead bits for the sum.
-constexpr int kFixHead = 37;
+// backward kernel, BEFORE the gradients are rounded to their storage type: rounding can lift a value by at most one ulp of
+// bf16, 2^-8 relative, which the bound below absorbs by using the NEXT power of two).  A contribution is w * g with
+// 0 <= w <= 1, so |v| <= gmax < 2^(E+1) with E = exponent(gmax); pass 1 may merge the up to 64 same-cell contributions of a
+// wave into one record, so a record is bounded by 64 * 2^(E+1).
+// fixed = v * 2^(kFixHead - E - 1) keeps a single contribution below 2^kFixHead and a record below 2^(kFixHead + 6): with
+// kFixHead = 31 that leaves 63 - 37 = 26 bits for the sum (6.7e7 maximal records per row) and 31 significant bits below
+// the largest gradient -- seven more than the fp32 mantissa the atomic path accumulates with.
+// A non-finite gradient anywhere in the step makes the exponent field 255: the reducer then writes NaN into every row sum
+// (the atomic path would have poisoned the touched rows; the divergence stays visible instead of turning into garbage).
+constexpr int kFixHead = 31;
+__device__ __forceinline__ bool fixed_nonfinite(uint32_t gmax_bits) { return ((gmax_bits >> 23) & 0xffu) == 0xffu; }
 __device__ __forceinline__ int fixed_shift(uint32_t gmax_bits) {
     const int e = (int)((gmax_bits >> 23) & 0xffu);          // biased exponent of gmax; 0 -> all gradients are zero
-    return e == 0 ? 0 : kFixHead - (e - 127) - 1;
+    return (e == 0 || e == 255) ? 0 : kFixHead - (e - 127) - 1;
 }
 // fp32 -> 64-bit fixed point round(v * 2^shift), branch-free: the product is exact in double, and adding 1.5 * 2^52
-// leaves the (two's complement) integer in the low mantissa bits for |v * 2^shift| < 2^51 (here < 2^38).
+// leaves the (two's complement) integer in the low mantissa bits for |v * 2^shift| < 2^51 (here < 2^38 per record).
 __device__ __forceinline__ long long to_fixed(float v, double scale) {
     const double d = (double)v * scale + 6755399441055744.0;
     return __double_as_longlong(d) - 0x4338000000000000ll;
@@ -168,7 +176,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ++ch) g[ch] = 0.0f;
         }
-        dispatch_mode(m.mode, [&](auto mode_tag) {
+        dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
             constexpr uint32_t MODE = decltype(mode_tag)::value;
             float w[8];
             cell_corners<MODE, 3>(m, frac, pg, w, row);
@@ -178,25 +186,30 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w[c] * g[ch];
         });
         // Cells wider than the sample spacing (wave-uniform decision): consecutive samples of a ray that fall into the
-        // same cell hit the same 8 rows.  Merge each run of equal cells inside the wave (segmented inclusive scan);
-        // only the last lane of a run emits records.
+        // same cell hit the same 8 rows.  Merge each run of equal cells with a segmented inclusive scan; only the last
+        // lane of a run emits records.  Runs are cut at 16-lane rows: the scan then moves its operands with DPP row shifts
+        // (a modifier of the VALU instruction) instead of 6 x 16 trips through the LDS crossbar (ds_bpermute) -- on the
+        // three coarse levels that merge, the scan used to cost more than the records it saves (per-level launches:
+        // 0.078 ms against 0.066 ms for a hashed level).  A cut costs at most one extra record set per 16 samples.
         bool emit = true;
         if (m.scale * spacing < 0.75f) {
-            const uint64_t cell = (uint64_t)pg[0] | ((uint64_t)pg[1] << 21) | ((uint64_t)pg[2] << 42);
-            const uint64_t prev = __shfl_up(cell, 1, 64);
-            const uint64_t heads = __ballot(lane == 0u || cell != prev);
+            const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2];        // merging levels have < 2^16 cells per axis
+            const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
+            const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
             const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                const bool take = lane >= start + d;
-#pragma unroll
+            const uint32_t len = lane - start;                               // my position inside the run (same row)
+            auto fold = [&](auto shift_tag) {
+                constexpr uint32_t d = decltype(shift_tag)::value;
+                const float take = len >= d ? 1.0f : 0.0f;          // val += shifted * take: one v_fmac with a DPP operand per value
+#pragma unroll                                                       // (the product with 0 / 1 is exact, so this IS the masked add)
                 for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) {
-                        const float t = __shfl_up(val[c][ch], d, 64);
-                        if (take) val[c][ch] += t;
-                    }
-            }
+                    for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = __builtin_fmaf(dpp_row_shr<d>(val[c][ch]), take, val[c][ch]);
+            };
+            fold(std::integral_constant<uint32_t, 1>{});
+            fold(std::integral_constant<uint32_t, 2>{});
+            fold(std::integral_constant<uint32_t, 4>{});
+            fold(std::integral_constant<uint32_t, 8>{});
             emit = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
         }
         // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
@@ -290,14 +303,16 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 // Accumulators are 64-bit FIXED POINT updated with ds_add_u64: integer LDS atomics run at 4.7 lane-ops/clk/CU on
 // gfx950 against 2.46 for ds_add_f64 and 0.33 for ds_add_f32 (tools/lds_atomic_bench.hip).  Integer addition is
 // associative, so the reduction is bit-reproducible from run to run.  The scale follows the largest feature gradient of
-// the step (fixed_shift): 37 significant bits below it, 26 bits of headroom above for the sum.
+// the step (fixed_shift): 31 significant bits below it, 26 bits of headroom above for the sum of merged records.
 template <uint32_t C, typename Rec>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, float *__restrict__ sums, const uint32_t *__restrict__ gmax_bits,
                       uint32_t H, uint32_t level_base, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int shift = fixed_shift(*gmax_bits);
+    const uint32_t gbits = *gmax_bits;
+    const int shift = fixed_shift(gbits);
+    const bool poison = fixed_nonfinite(gbits);
     const double scale = ldexp(1.0, shift);
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t T_ = blockDim.x, CAP = plan.slot_cap;
@@ -387,14 +402,14 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
         float *__restrict__ dst = sums + (((size_t)ly << plan.log2_nb) + bucket) * sums_rows(plan) * C;
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            dst[i] = (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
+            dst[i] = poison ? __builtin_nanf("") : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
         }
     } else {
         float *__restrict__ gg = grad_table + (size_t)off * C;
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
             atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb, twist) * C + ch,
-                      (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));             // one add per row and split
+                      poison ? __builtin_nanf("") : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));   // one add per row and split
         }
     }
 }

@@ -35,6 +35,7 @@ class _LazyRays:
         if isinstance(key, tuple):                       # rays[index, rows, cols]
             index, rows, cols = key
             pix = int(index) * self._g.pixels_per_projection + rows.long() * self._g.W + cols.long()
+            pix = pix.to(self._g.device)                 # index tensors may live on the host, like indexing the reference's tensor
             return self._g.rays_for_pixels(pix.reshape(-1)).reshape(list(pix.shape) + [8])
         return self._g.rays_for_projection(int(key)).reshape(self._g.H, self._g.W, 8)
 
@@ -42,7 +43,9 @@ class _LazyRays:
 class TIGREDataset(Dataset):
     """TIGRE dataset (`path` may also be an already loaded dict with the pickle schema)."""
 
-    def __init__(self, path, n_rays=1024, type="train", device="cuda"):
+    def __init__(self, path, n_rays=1024, type="train", device="cuda", shard=(0, 1), seed=None):
+        """`shard = (rank, world)` (data parallel): every rank draws the SAME `n_rays` pixels per item (shared generator
+        seed) and keeps its contiguous slice, so the union over ranks is exactly the single-process batch."""
         super().__init__()
         if isinstance(path, dict):
             data = path
@@ -72,8 +75,17 @@ class TIGREDataset(Dataset):
         self.coords = torch.stack([rows, cols], -1).reshape(-1, 2).float()     # (row, col) like tigre.py:256-276
         self.image = torch.tensor(np.asarray(data["image"]), dtype=torch.float32, device=self.device)
         self._voxels = None
-        # valid (non-zero) pixels per projection, found once (the reference recomputes |proj| > 0 per item)
-        self._valid = None
+        # valid (non-zero) pixels per projection, found once (the reference recomputes |proj| > 0 per item, tigre.py:356):
+        # after the first pass over the scan an item costs no host synchronisation at all
+        self._valid = {}
+        self._mask = {}                                  # ptycho mask per projection (train.py:59-60 rebuilds it every step)
+        self.shard = (int(shard[0]), int(shard[1]))
+        if self.shard[1] > 1 and seed is None:
+            seed = 0                                     # ranks must agree on the pixel draw
+        self._generator = None
+        if seed is not None:
+            self._generator = torch.Generator(device=self.device)
+            self._generator.manual_seed(int(seed))
 
     @property
     def voxels(self):
@@ -85,8 +97,21 @@ class TIGREDataset(Dataset):
         return self.n_samples
 
     def _valid_pixels(self, index):
-        flat = self.projs[index].reshape(-1)
-        return torch.nonzero(flat.abs() > 0, as_tuple=False).reshape(-1)
+        index = int(index)
+        hit = self._valid.get(index)
+        if hit is None:
+            flat = self.projs[index].reshape(-1)
+            hit = self._valid[index] = torch.nonzero(flat.abs() > 0, as_tuple=False).reshape(-1)
+        return hit
+
+    def ptycho_mask(self, index, threshold=0.007):
+        """`get_ptycho_mask(full_proj[index])` (util.py:196-205), computed once per projection."""
+        from .utils import get_ptycho_mask
+        index = int(index)
+        hit = self._mask.get(index)
+        if hit is None:
+            hit = self._mask[index] = get_ptycho_mask(self.full_proj[index], threshold=threshold)
+        return hit
 
     def sample_pixels(self, index, n_rays=None, generator=None):
         """`n_rays` distinct valid pixels of projection `index` (tigre.py:356-359: choice without replacement),
@@ -95,12 +120,18 @@ class TIGREDataset(Dataset):
         valid = self._valid_pixels(index)
         if valid.numel() < n_rays:
             raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        if generator is None:
+            generator = self._generator
         perm = torch.randperm(valid.numel(), device=self.device, generator=generator)[:n_rays]
         return valid[perm]
 
     def __getitem__(self, index):
         if self.type == "train":
             pix = self.sample_pixels(index)
+            if self.shard[1] > 1:
+                from .dist import shard_range
+                begin, end = shard_range(pix.numel(), *self.shard)
+                pix = pix[begin:end]
             W = self.raygen.W
             select_coords = torch.stack([pix // W, pix % W], -1)
             rays = self.raygen.rays_for_pixels(index * self.raygen.pixels_per_projection + pix)
@@ -108,24 +139,31 @@ class TIGREDataset(Dataset):
             out = {"projs": projs, "rays": rays, "coords": select_coords}
             if self.full_proj is not None:
                 out["full_proj"] = self.full_proj[index]
+                out["mask"] = self.ptycho_mask(index).reshape(-1)[pix]      # extra key: the mask at the sampled pixels
             return out
         return {"projs": self.projs[index], "rays": self.rays[index]}
 
 
-def synthetic_scan(n_voxel=64, n_train=50, n_val=8, mode="cone", tilt_angle=0, seed=0, device="cpu", full_proj=False):
+def synthetic_scan(n_voxel=64, n_train=50, n_val=8, mode="cone", tilt_angle=0, seed=0, device="cpu", full_proj=False,
+                   geometry=None, train_angles=None):
     """A complete in-memory scan with the pickle schema, from the analytic phantom (no data ships with the reference).
-    Train angles: linspace(0, pi, n+1)[:-1] (generateData.py:175); val angles: sorted U(0, pi) with seed 1."""
+    Train angles: linspace(0, pi, n+1)[:-1] (generateData.py:175) unless `train_angles` (radians) is given; val angles:
+    sorted U(0, pi) with seed 1.  `geometry` overrides the default scanner dict (e.g. the 256 x 356 laminography detector)."""
     from . import phantom
     from .geometry import angle2pose  # noqa: F401  (documented dependency)
 
-    data = phantom.scan_geometry(n_voxel, mode, tilt_angle)
+    data = dict(geometry) if geometry is not None else phantom.scan_geometry(n_voxel, mode, tilt_angle)
+    tilt_angle = data.get("tilt_angle", tilt_angle)
+    if train_angles is not None:
+        n_train = len(train_angles)
     geo = ConeGeometry(data)
     table = phantom.ellipsoid_table(seed=seed, extent=float(geo.sVoxel[0]) / 2)
     if tilt_angle:                                       # flat sample for laminography
         table["c"][:, 2] *= 0.3
         table["a"][:, 2] *= 0.3
     rng = np.random.RandomState(1)
-    splits = {"train": np.linspace(0, np.pi, n_train + 1)[:-1], "val": np.sort(rng.uniform(0, np.pi, n_val))}
+    splits = {"train": np.linspace(0, np.pi, n_train + 1)[:-1] if train_angles is None else np.asarray(train_angles, dtype=np.float64),
+              "val": np.sort(rng.uniform(0, np.pi, n_val))}
     dev = torch.device(device)
     for name, angles in splits.items():
         H, W = int(geo.nDetector[1]), int(geo.nDetector[0])

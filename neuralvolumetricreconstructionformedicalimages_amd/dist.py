@@ -48,6 +48,60 @@ def global_mean_weights(mask, group=None):
     return m / total.clamp(min=1.0)
 
 
+def default_bucket_levels(num_levels):
+    """Level ranges in the order the gradient scatter finishes them: two halves, fine levels first.  The reducer then
+    still runs in full rounds of 256 workgroups (64 row buckets x 8 levels = 512), the first half's all-reduce hides behind
+    the second half's bin + reduce passes, and the exchange left exposed is the coarse half, whose dense levels are small
+    (22.5 of 57 MB at L = 16, T = 2^19)."""
+    L = int(num_levels)
+    return [(L // 2, L), (0, L // 2)] if L >= 2 else [(0, L)]
+
+
+def grad_bucket_slices(offsets, level_dim, bucket_levels):
+    """Element ranges [begin, end) of the flat table-gradient buffer for each bucket of levels (`offsets` = row offsets
+    per level, [L+1]; a level's rows are contiguous, hashgrid.py:92-102).  Raises unless the buckets are disjoint level
+    ranges that cover every level exactly once."""
+    offs = [int(v) for v in offsets]
+    L = len(offs) - 1
+    buckets = [(int(a), int(b)) for a, b in bucket_levels]
+    covered = sorted(l for a, b in buckets for l in range(a, b))
+    if covered != list(range(L)) or any(a >= b for a, b in buckets):
+        raise ValueError(f"bucket_levels {buckets} must be disjoint, non-empty level ranges covering 0..{L}")
+    return [(offs[a] * level_dim, offs[b] * level_dim) for a, b in buckets]
+
+
+def aligned_update_slices(slices, multiple=4):
+    """Element ranges for the per-bucket optimiser pass, given the exchange slices in the order their sums arrive.
+
+    The Adam kernel works on 16-byte groups, so a boundary between two buckets that is not a multiple of `multiple`
+    elements is moved to the next / previous multiple in favour of the bucket whose sum arrives LATER: collectives complete
+    in issue order, so when the later bucket is ready the ragged elements of its neighbour are too.  The ranges still tile
+    the same elements exactly once."""
+    order = {rng: i for i, rng in enumerate(slices)}
+    tiled = sorted(slices)
+    for (a0, b0), (a1, b1) in zip(tiled, tiled[1:]):
+        if b0 != a1:
+            raise ValueError("exchange slices must be contiguous")
+    bounds = [tiled[0][0]]
+    for left, right in zip(tiled, tiled[1:]):
+        x = left[1]
+        if x % multiple:
+            x = x + (-x) % multiple if order[left] > order[right] else x - x % multiple
+        bounds.append(x)
+    bounds.append(tiled[-1][1])
+    moved = {rng: (bounds[i], bounds[i + 1]) for i, rng in enumerate(tiled)}
+    return [moved[rng] for rng in slices]
+
+
+def all_reduce_buckets_(flat, slices, group=None):
+    """Sum each [begin, end) slice of the flat buffer over the group, one collective per slice, in list order (every rank
+    must use the same list).  The engine issues exactly these collectives, each as soon as its bucket's event has fired."""
+    if group is None:
+        return
+    for a, b in slices:
+        dist.all_reduce(flat[a:b], group=group)
+
+
 def all_reduce_sum_(tensors, group=None):
     """In-place sum of each tensor over the group (no-op without a group)."""
     if group is None:

@@ -36,6 +36,8 @@ class _hash_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, base_resolution, calc_grad_inputs=False):
         # inputs [B, D] float in [0,1]; embeddings [sO, C]; offsets [L+1] int32; returns [B, L*C]
+        # calc_grad_inputs: False / True (exact input gradient) / _abi.GRAD_INPUTS_REFERENCE (the reference's dy_dx,
+        # level scale missing, `nd > gd` dimension pick -- only for comparing against reference runs)
         if torch.is_autocast_enabled():                   # reference: custom_fwd(cast_inputs=torch.half)
             embeddings = embeddings.half()
         inputs = inputs.contiguous().float()
@@ -78,7 +80,7 @@ hash_encode = _hash_encode.apply
 
 class HashEncoder(nn.Module):
     def __init__(self, input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
-                 strict_range=True):
+                 strict_range=True, reference_compat=False):
         super().__init__()
         self.input_dim = input_dim
         self.num_levels = num_levels
@@ -87,6 +89,7 @@ class HashEncoder(nn.Module):
         self.base_resolution = base_resolution
         self.output_dim = num_levels * level_dim
         self.strict_range = strict_range
+        self.reference_compat = reference_compat      # input gradients as the reference computes them (App. A-3)
         if input_dim not in (2, 3) or level_dim not in (1, 2, 4, 8):
             raise RuntimeError("GridEncoding: C must be 1, 2, 4, or 8.")        # hashencoder.cu:310,324
         self.max_params = 2 ** log2_hashmap_size
@@ -144,8 +147,10 @@ class HashEncoder(nn.Module):
             inputs = x01
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
-        outputs = hash_encode(inputs, self.embeddings, self._device_offsets(inputs.device), self.base_resolution,
-                              inputs.requires_grad)
+        calc = inputs.requires_grad
+        if calc and self.reference_compat:
+            calc = _abi.GRAD_INPUTS_REFERENCE
+        outputs = hash_encode(inputs, self.embeddings, self._device_offsets(inputs.device), self.base_resolution, calc)
         return outputs.view(prefix_shape + [self.output_dim])
 
 

@@ -6,8 +6,10 @@ Replaces, for the canonical NAF network, what reference src/trainer.py:134-142 +
     `encoder.embeddings` / `layers.i.weight|bias` are views of them, so state_dict() keeps the reference keys;
   * with a 16-bit table the fp32 master is updated by Adam and the bf16/fp16 shadow the kernels gather from is
     written in the same pass; the gradient buffer is zeroed in that pass too;
-  * data parallel (one process per GPU): gradients are summed with one RCCL all-reduce per buffer between the
-    backward and the optimiser (see dist.py).
+  * data parallel (one process per GPU, rays sharded, model replicated): the table gradient is finished bucket by bucket
+    (level groups, fine levels first; `naf_render_train_bucketed` records an event per bucket), each bucket's slice of the
+    flat gradient buffer is all-reduced (RCCL) on a side stream while the next bucket is still being binned and reduced,
+    and Adam runs per bucket as soon as its sum has arrived -- only the last, smallest exchange is exposed (see dist.py).
 """
 from __future__ import annotations
 
@@ -21,7 +23,8 @@ from . import fused
 
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
-                 mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384):
+                 mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384, scatter_mode=None, cfg_flags=None,
+                 bucket_levels=None):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -36,6 +39,7 @@ class NAFEngine:
         self.step_count = 0
         self.rays_seen = 0
         self.process_group = process_group
+        self.scatter_mode, self.cfg_flags = scatter_mode, cfg_flags     # None: fused.scatter_mode() default (auto)
 
         # ---- flat fp32 master parameters; module parameters become views ---------------------------------
         self.emb = enc.embeddings.data.float().contiguous()
@@ -70,12 +74,61 @@ class NAFEngine:
         # Optional multi-stream execution: the batch is cut into chunks that run their whole forward/backward pipeline on
         # alternating HIP streams, so the gather-bound, VALU-bound and store-bound kernels of different chunks overlap.
         # Each extra stream owns a gradient buffer, a workspace and a loss cell; they are summed before Adam.
+        self._dp = None
+        if process_group is not None:
+            if int(n_streams) > 1:
+                raise ValueError("NAFEngine: n_streams > 1 cannot be combined with a process group (the bucket events are "
+                                 "recorded by the one launch that owns the gradient buffer)")
+            self._init_data_parallel(bucket_levels)
         self.n_streams = max(1, int(n_streams))
         self.chunk_rays = int(chunk_rays)
         self._lanes = []
         for _ in range(self.n_streams - 1):
             self._lanes.append({"stream": torch.cuda.Stream(device=dev), "emb_g": torch.zeros_like(self.emb),
                                 "mlp_g": torch.zeros_like(self.mlp), "loss": torch.zeros(1, device=dev), "ws": None})
+
+    # ---- data parallel -------------------------------------------------------------------------------------
+    def _init_data_parallel(self, bucket_levels):
+        """Buckets = level ranges in the order the scatter finishes them (dist.default_bucket_levels)."""
+        from . import dist as naf_dist
+        L = self.net.encoder.num_levels
+        if bucket_levels is None:
+            bucket_levels = naf_dist.default_bucket_levels(L)
+        bucket_levels = [(int(a), int(b)) for a, b in bucket_levels]
+        if len(bucket_levels) > _abi.MAX_GRAD_BUCKETS:
+            raise ValueError(f"at most {_abi.MAX_GRAD_BUCKETS} gradient buckets")
+        n_emb = self.emb.numel()
+        o_mlp = (n_emb + 63) // 64 * 64
+        dp = {"levels": bucket_levels, "comm": torch.cuda.Stream(device=self.device), "time": False, "timings": []}
+        # torch creates the underlying hipEvent_t at the first record(): do that now so the handles can be handed to the library
+        def event():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return ev
+        dp["ready"] = [event() for _ in bucket_levels]
+        dp["mlp_ready"] = event()
+        dp["done"] = [event() for _ in bucket_levels]
+        dp["mlp_done"] = event()
+        dp["slices"] = naf_dist.grad_bucket_slices(self.offsets.tolist(), self.net.encoder.level_dim, bucket_levels)
+        dp["update_slices"] = naf_dist.aligned_update_slices(dp["slices"])              # Adam works on 16-byte groups
+        dp["mlp_slice"] = (o_mlp, self.grad_flat.numel())                              # MLP gradient + loss cell
+        st = _abi.GradBuckets()
+        st.n_buckets = len(bucket_levels)
+        for i, (a, b) in enumerate(bucket_levels):
+            st.level_begin[i], st.level_end[i] = a, b
+            st.ready[i] = dp["ready"][i].cuda_event
+        st.mlp_ready = dp["mlp_ready"].cuda_event
+        dp["struct"] = st
+        self._dp = dp
+
+    def broadcast_parameters(self, src=0):
+        """Every rank starts from rank `src`'s table and MLP (and refreshes its 16-bit shadow)."""
+        if self.process_group is None:
+            return
+        import torch.distributed as dist
+        for t in (self.emb, self.mlp):
+            dist.broadcast(t, src=src, group=self.process_group)
+        self.sync_from_module()
 
     # -------------------------------------------------------------------------------------------------------
     def _cfg(self, ray_base=0):
@@ -85,7 +138,9 @@ class NAFEngine:
                               table_dtype=_abi.dtype_code(self.table_dtype), mlp_precision=int(self.mlp_precision),
                               last_activation=fused.LAST_ACTIVATIONS[self.net.last_activation],
                               seed=(self.seed + 0x9E3779B97F4A7C15 * (self.step_count + 1)) & (2 ** 64 - 1),
-                              ray_index_base=int(ray_base), log2_hashmap_size=int(enc.log2_hashmap_size))
+                              ray_index_base=int(ray_base), log2_hashmap_size=int(enc.log2_hashmap_size),
+                              scatter_mode=fused._default_scatter_mode if self.scatter_mode is None else int(self.scatter_mode),
+                              flags=fused._default_flags if self.cfg_flags is None else int(self.cfg_flags))
 
     @property
     def table(self):
@@ -94,10 +149,13 @@ class NAFEngine:
     def _launch(self, rays, target, weight, t_rand, ray_base, acc, emb_g, mlp_g, loss, ws):
         n = rays.shape[0]
         cfg = self._cfg(ray_base)
-        _abi.check(_abi.lib().naf_render_train(
-            _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
-            _abi.ptr(self.mlp), _abi.ptr(acc), _abi.ptr(emb_g), _abi.ptr(mlp_g), _abi.ptr(loss), n,
-            ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_train")
+        args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
+                _abi.ptr(self.mlp), _abi.ptr(acc), _abi.ptr(emb_g), _abi.ptr(mlp_g), _abi.ptr(loss), n, ctypes.byref(cfg), _abi.ptr(ws))
+        if self._dp is not None and emb_g is self.emb_g:
+            _abi.check(_abi.lib().naf_render_train_bucketed(*args, ctypes.byref(self._dp["struct"]), _abi.stream_ptr()),
+                       "render_train_bucketed")
+        else:
+            _abi.check(_abi.lib().naf_render_train(*args, _abi.stream_ptr()), "render_train")
 
     def backward(self, rays, target, weight, t_rand=None, ray_base=0):
         """Forward + weighted squared error + backward: fills the gradient buffers, returns acc [n]."""
@@ -158,30 +216,95 @@ class NAFEngine:
         return int(out.value)
 
     def all_reduce_grads(self):
+        """Single-buffer form (one all-reduce of table + MLP gradients + loss); the training step uses the bucketed,
+        overlapped form below.  Kept for callers that fill the gradient buffers themselves."""
         if self.process_group is None:
             return
         import torch.distributed as dist
         dist.all_reduce(self.grad_flat, group=self.process_group)       # table + MLP gradients + loss (sum over ranks)
 
+    def _adam(self, param, m, v, g, lp, lp_code, what, grad_scale=1.0):
+        b1, b2 = self.betas
+        _abi.check(_abi.lib().naf_adam_step(_abi.ptr(param), _abi.ptr(m), _abi.ptr(v), _abi.ptr(g), _abi.ptr(lp), lp_code,
+                                            param.numel(), self.lr, b1, b2, self.eps, self.step_count, grad_scale, 1,
+                                            _abi.stream_ptr()), what)
+
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
-        b1, b2 = self.betas
-        lp = _abi.ptr(self.emb_lp)
         lp_code = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
-        lib = _abi.lib()
-        _abi.check(lib.naf_adam_step(_abi.ptr(self.emb), _abi.ptr(self.emb_m), _abi.ptr(self.emb_v), _abi.ptr(self.emb_g), lp,
-                                     lp_code, self.emb.numel(), self.lr, b1, b2, self.eps, self.step_count, grad_scale, 1,
-                                     _abi.stream_ptr()), "adam_step(table)")
-        _abi.check(lib.naf_adam_step(_abi.ptr(self.mlp), _abi.ptr(self.mlp_m), _abi.ptr(self.mlp_v), _abi.ptr(self.mlp_g), None,
-                                     0, self.mlp.numel(), self.lr, b1, b2, self.eps, self.step_count, grad_scale, 1,
-                                     _abi.stream_ptr()), "adam_step(mlp)")
+        self._adam(self.emb, self.emb_m, self.emb_v, self.emb_g, self.emb_lp, lp_code, "adam_step(table)", grad_scale)
+        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)", grad_scale)
+
+    def _exchange_and_step(self):
+        """Data-parallel tail of a step.  On the side stream, per bucket in the order the scatter finishes them: wait for
+        the bucket's event, all-reduce its slice of the flat gradient buffer.  On the main stream: as each sum arrives,
+        Adam on exactly that slice of the parameters (so the last exchange overlaps the first bucket's update)."""
+        import torch.distributed as dist
+        dp = self._dp
+        main, comm = torch.cuda.current_stream(self.device), dp["comm"]
+        timing = dp["time"]
+        marks = []
+        order = [("mlp", dp["mlp_ready"], dp["mlp_done"], dp["mlp_slice"])]
+        order += [(i, dp["ready"][i], dp["done"][i], dp["slices"][i]) for i in range(len(dp["levels"]))]
+        with torch.cuda.stream(comm):
+            for tag, ready, done, (a, b) in order:
+                comm.wait_event(ready)
+                if timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(comm)
+                dist.all_reduce(self.grad_flat[a:b], group=self.process_group)
+                done.record(comm)
+                if timing:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(comm)
+                    marks.append((t0, t1))
+        if timing:
+            c0 = torch.cuda.Event(enable_timing=True)
+            c0.record(main)                                      # end of this rank's own compute
+        self.step_count += 1
+        lp_code = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
+        emb, m, v, g = (t.view(-1) for t in (self.emb, self.emb_m, self.emb_v, self.emb_g))
+        lp = None if self.emb_lp is None else self.emb_lp.view(-1)
+        waited = []
+        for i, (a, b) in enumerate(dp["update_slices"]):
+            main.wait_event(dp["done"][i])
+            if timing:
+                w = torch.cuda.Event(enable_timing=True)
+                w.record(main)
+                waited.append(w)
+            self._adam(emb[a:b], m[a:b], v[a:b], g[a:b], None if lp is None else lp[a:b], lp_code, "adam_step(table bucket)")
+        main.wait_event(dp["mlp_done"])
+        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
+        if timing:
+            c1 = torch.cuda.Event(enable_timing=True)
+            c1.record(main)
+            dp["timings"].append((marks, c0, waited, c1))
+
+    def comm_timing(self, enable=True):
+        """Switch on event timing of the exchange (bench.py); `comm_report()` then returns per-step averages."""
+        if self._dp is not None:
+            self._dp["time"], self._dp["timings"] = bool(enable), []
+
+    def comm_report(self):
+        """-> {"allreduce_ms_per_step": time the collectives were in flight on the side stream (sum over buckets),
+        "exposed_ms_per_step": time the main stream spent between the end of its own compute and the last Adam launch minus the
+        Adam kernels themselves, i.e. what the exchange adds to the step}.  Synchronises."""
+        if self._dp is None or not self._dp["timings"]:
+            return None
+        torch.cuda.synchronize(self.device)
+        steps = self._dp["timings"]
+        in_flight = sum(sum(a.elapsed_time(b) for a, b in marks) for marks, _, _, _ in steps) / len(steps)
+        tail = sum(c0.elapsed_time(c1) for _, c0, _, c1 in steps) / len(steps)
+        return {"allreduce_ms_per_step": in_flight, "tail_ms_per_step": tail}
 
     def train_step(self, rays, target, weight, t_rand=None, ray_base=0):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync)."""
         self.backward(rays, target, weight, t_rand, ray_base)
-        self.all_reduce_grads()
-        self.optimizer_step()
+        if self._dp is not None:
+            self._exchange_and_step()
+        else:
+            self.optimizer_step()
         self.rays_seen += rays.shape[0]
         return self.loss
 

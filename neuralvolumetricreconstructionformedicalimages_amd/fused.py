@@ -6,6 +6,7 @@ The reference evaluates the same maths as ~40 ATen/cuBLAS launches per 200-ray c
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 
 import torch
@@ -23,7 +24,29 @@ def _bump(device):
     return _feature_gen[device]
 
 
-def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_base=0):
+_default_scatter_mode = _abi.SCATTER_AUTO
+_default_flags = 0
+
+
+@contextlib.contextmanager
+def scatter_mode(mode, flags=None):
+    """Default `naf_render_cfg.scatter_mode` (and optionally `.flags`) of every cfg built inside the block (tests and
+    diagnostics compare the binned scatter with the reference's atomics this way).  The value travels in the cfg of each
+    call; the library itself keeps no mode."""
+    global _default_scatter_mode, _default_flags
+    if mode not in (_abi.SCATTER_AUTO, _abi.SCATTER_ATOMIC, _abi.SCATTER_BINNED):
+        raise ValueError("scatter mode must be SCATTER_AUTO (0), SCATTER_ATOMIC (1) or SCATTER_BINNED (2)")
+    saved = (_default_scatter_mode, _default_flags)
+    _default_scatter_mode = mode
+    if flags is not None:
+        _default_flags = int(flags)
+    try:
+        yield
+    finally:
+        _default_scatter_mode, _default_flags = saved
+
+
+def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_base=0, scatter=None, flags=None):
     enc = net.encoder
     table_dtype = _abi.dtype_code(enc.embeddings.dtype)
     if mlp_precision is None:          # parity mode for fp32 tables, bf16 matrix cores for 16-bit tables
@@ -31,7 +54,9 @@ def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_ba
     return _abi.RenderCfg(n_samples=int(n_samples), perturb=int(bool(perturb)), bound=float(net.bound),
                           L=enc.num_levels, C=enc.level_dim, H=enc.base_resolution, table_dtype=table_dtype,
                           mlp_precision=int(mlp_precision), last_activation=LAST_ACTIVATIONS[net.last_activation],
-                          seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), log2_hashmap_size=int(enc.log2_hashmap_size))
+                          seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), log2_hashmap_size=int(enc.log2_hashmap_size),
+                          scatter_mode=_default_scatter_mode if scatter is None else int(scatter),
+                          flags=_default_flags if flags is None else int(flags))
 
 
 def workspace(cfg, n_points, device):

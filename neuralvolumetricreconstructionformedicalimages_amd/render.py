@@ -76,38 +76,38 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0.0):
         acc = _Integrate.apply(raw0, z_vals.contiguous().float(), rays)
     else:
         raise RuntimeError("raw2outputs: tensors must live on the GPU (no CPU path)")
-    if raw.shape[-1] == 1:
-        eps = torch.ones_like(raw[:, :1, -1]) * 1e-10
-        weights = torch.cat([eps, torch.abs(raw[:, 1:, -1] - raw[:, :-1, -1])], dim=-1)
-        weights = weights / torch.max(weights)
-    elif raw.shape[-1] == 2:
-        weights = raw[..., 1] / torch.max(raw[..., 1])
+    # importance weights of the fine pass (render.py:203-211): |sigma jump| between neighbouring samples (1e-10 for the
+    # first), or the network's second output channel; both scaled by the largest weight of the WHOLE chunk (App. A-10)
+    n_channels = raw.shape[-1]
+    if n_channels == 1:
+        sigma = raw[..., 0]
+        weights = torch.nn.functional.pad((sigma[:, 1:] - sigma[:, :-1]).abs(), (1, 0), value=1e-10)
+    elif n_channels == 2:
+        weights = raw[..., 1]
     else:
         raise NotImplementedError("Wrong raw shape")
-    return acc, weights
+    return acc, weights / weights.max()
 
 
 def sample_pdf(bins, weights, N_samples, det=False):
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    """Inverse-transform sampling of the piecewise-constant density `weights` over the intervals between `bins`
+    (render.py:215-247): [n, M] bins, [n, M-1] weights -> [n, N_samples] depths.  `det` takes evenly spaced quantiles."""
+    mass = weights + 1e-5                                            # keeps empty rays samplable
+    cdf = torch.cumsum(mass / mass.sum(-1, keepdim=True), -1)
+    cdf = torch.nn.functional.pad(cdf, (1, 0))                       # cdf[..., 0] = 0 : one value per bin edge
+    rows = list(cdf.shape[:-1])
     if det:
-        u = torch.linspace(0.0, 1.0, steps=N_samples, device=cdf.device).expand(list(cdf.shape[:-1]) + [N_samples])
+        u = torch.linspace(0.0, 1.0, steps=N_samples, device=cdf.device).expand(rows + [N_samples]).contiguous()
     else:
-        u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=cdf.device)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below = torch.clamp(inds - 1, min=0)
-    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
-    inds_g = torch.stack([below, above], -1)
-    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
-    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
-    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
-    denom = cdf_g[..., 1] - cdf_g[..., 0]
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    t = (u - cdf_g[..., 0]) / denom
-    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+        u = torch.rand(rows + [N_samples], device=cdf.device)
+    upper = torch.searchsorted(cdf, u, right=True)                   # first edge whose cdf exceeds u
+    lower = (upper - 1).clamp_min(0)
+    upper = upper.clamp_max(cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = cdf.gather(-1, lower), cdf.gather(-1, upper)
+    z_lo, z_hi = bins.gather(-1, lower), bins.gather(-1, upper)
+    span = cdf_hi - cdf_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)     # flat stretch of the cdf: stay on the lower edge
+    return z_lo + (u - cdf_lo) / span * (z_hi - z_lo)
 
 
 def _points(rays, z_vals, bound):

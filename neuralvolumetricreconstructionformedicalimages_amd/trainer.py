@@ -60,18 +60,20 @@ class _EngineOptimizer:
 
 
 class _StepLR:
-    """torch.optim.lr_scheduler.StepLR semantics (lr = base * gamma ** (epoch // step_size)) for either optimiser."""
+    """torch.optim.lr_scheduler.StepLR in its chainable form, for either optimiser: every `step_size`-th call multiplies
+    the learning rate THE OPTIMISER CURRENTLY HOLDS by gamma.  The rate is therefore part of the optimiser state: a
+    resumed run continues from the decayed rate its checkpoint stored (trainer.py:54-66 -- the reference builds the
+    scheduler before it loads the checkpoint and never restores the scheduler itself, so its counter restarts at 0)."""
 
     def __init__(self, optimizer, step_size, gamma):
         self.optimizer, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
-        self.base = float(optimizer.param_groups[0]["lr"])
         self.last_epoch = 0
 
     def step(self):
         self.last_epoch += 1
-        lr = self.base * self.gamma ** (self.last_epoch // self.step_size)
-        for g in self.optimizer.param_groups:
-            g["lr"] = lr
+        if self.last_epoch % self.step_size == 0:
+            for g in self.optimizer.param_groups:
+                g["lr"] = g["lr"] * self.gamma
         if hasattr(self.optimizer, "sync_lr"):
             self.optimizer.sync_lr()
 
@@ -84,6 +86,12 @@ class Trainer:
         self.global_step = 0
         self.conf = cfg
         self.device = torch.device(device)
+        # data parallel when launched one process per GPU (torchrun contract: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*);
+        # rays of a step are sharded over the ranks, the model is replicated
+        self.rank, self.world, self.group = 0, 1, None
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            from . import dist as naf_dist
+            self.rank, self.world, _, self.group = naf_dist.init_from_env(self.device.type)
         self.n_fine = cfg["render"]["n_fine"]
         self.epochs = cfg["train"]["epoch"]
         self.i_eval = cfg["log"]["i_eval"]
@@ -92,6 +100,7 @@ class Trainer:
         self.n_rays = cfg["train"]["n_rays"]
         backend = cfg.get("backend", {}) or {}
         self.loss_mode = backend.get("loss", "chunk_sum")
+        self.i_log = int(cfg["log"].get("i_log", 100))      # steps between train/loss scalars (reading the loss synchronises)
 
         self.expdir = osp.join(cfg["exp"]["expdir"], cfg["exp"]["expname"])
         self.ckptdir = osp.join(self.expdir, "ckpt.tar")
@@ -100,7 +109,8 @@ class Trainer:
         os.makedirs(self.evaldir, exist_ok=True)
 
         data = cfg["exp"]["datadir"]
-        train_dset = Dataset(data, cfg["train"]["n_rays"], "train", device)
+        train_dset = Dataset(data, cfg["train"]["n_rays"], "train", device, shard=(self.rank, self.world),
+                             seed=backend.get("seed"))
         self.train_dset = train_dset
         self.eval_dset = Dataset(data, cfg["train"]["n_rays"], "val", device) if self.i_eval > 0 else None
         self.train_dloader = torch.utils.data.DataLoader(train_dset, batch_size=cfg["train"]["n_batch"])
@@ -118,11 +128,19 @@ class Trainer:
 
         self.engine = None
         want_fused = backend.get("engine", "fused") == "fused"
-        if want_fused and self.n_fine == 0 and self.net.fused_supported() and self.device.type == "cuda":
+        # the fused kernels have no noise input: a config that asks for raw_noise_std > 0 (render.py:186-190) runs through
+        # the module path, like any network shape the MFMA kernels are not specialised for
+        noise_free = float(cfg["render"].get("raw_noise_std", 0.0)) == 0.0
+        if want_fused and not noise_free:
+            print("[Trainer] render.raw_noise_std > 0: using the module back end (the fused engine is noise-free)")
+        if want_fused and noise_free and self.n_fine == 0 and self.net.fused_supported() and self.device.type == "cuda":
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
-                                    table_dtype=_DTYPES[backend.get("table_dtype", "float32")])
+                                    table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group)
+            self.engine.broadcast_parameters()
             self.optimizer = _EngineOptimizer(self.engine)
+        elif self.group is not None:
+            raise NotImplementedError("data-parallel training needs the fused engine (backend.engine: fused, n_fine: 0)")
         else:
             self.optimizer = torch.optim.Adam(params=grad_vars, lr=cfg["train"]["lrate"], betas=(0.9, 0.999))
         self.lr_scheduler = _StepLR(self.optimizer, cfg["train"]["lrate_step"], cfg["train"]["lrate_gamma"])
@@ -140,7 +158,7 @@ class Trainer:
                 self.engine.sync_from_module()
             self.global_step = self.epoch_start * len(self.train_dloader)
 
-        self.writer = SummaryWriter(self.expdir) if SummaryWriter is not None else _NullWriter()
+        self.writer = SummaryWriter(self.expdir) if (SummaryWriter is not None and self.rank == 0) else _NullWriter()
         self.writer.add_text("parameters", self.args2string(cfg), global_step=0)
 
     def args2string(self, hp):
@@ -152,13 +170,13 @@ class Trainer:
         iter_per_epoch = len(self.train_dloader)
         try:
             from tqdm import tqdm
-            pbar = tqdm(total=iter_per_epoch * self.epochs, leave=True)
+            pbar = tqdm(total=iter_per_epoch * self.epochs, leave=True, disable=self.rank != 0)
             pbar.update(self.epoch_start * iter_per_epoch)
         except Exception:                                  # pragma: no cover
             pbar = None
 
         for idx_epoch in range(self.epoch_start, self.epochs + 1):
-            if (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs) and self.i_eval > 0:
+            if self.i_eval > 0 and self.rank == 0 and (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs):
                 self.net.eval()
                 with torch.no_grad():
                     loss_test = self.eval_step(global_step=self.global_step, idx_epoch=idx_epoch)
@@ -176,7 +194,7 @@ class Trainer:
                                              f"lr={self.optimizer.param_groups[0]['lr']:.3g}")
                     pbar.update(1)
 
-            if (idx_epoch % self.i_save == 0 or idx_epoch == self.epochs) and self.i_save > 0 and idx_epoch > 0:
+            if self.i_save > 0 and idx_epoch > 0 and (idx_epoch % self.i_save == 0 or idx_epoch == self.epochs):
                 self.save_checkpoint(idx_epoch)
 
             self.writer.add_scalar("train/lr", self.optimizer.param_groups[0]["lr"], self.global_step)
@@ -184,6 +202,8 @@ class Trainer:
         print(f"Training complete! See logs in {self.expdir}")
 
     def save_checkpoint(self, idx_epoch):
+        if self.rank != 0:                                 # replicas are identical; rank 0 writes
+            return
         if osp.exists(self.ckptdir):
             copyfile(self.ckptdir, self.ckptdir_backup)
         print(f"[SAVE] epoch: {idx_epoch}/{self.epochs}, path: {self.ckptdir}")
@@ -196,12 +216,17 @@ class Trainer:
         """Per-ray loss weights: ptycho mask of the full projection sampled at the ray pixels (train.py:59-60,93-95,
         intended semantics of SURVEY.md App. A-6) and the reference's chunked mean (App. A-5)."""
         full_proj = data.get("full_proj")
-        if full_proj is not None:
+        if data.get("mask") is not None:                   # our dataset caches the mask per projection
+            mask = data["mask"].reshape(-1)
+        elif full_proj is not None:
             mask_full = get_ptycho_mask(full_proj.reshape(full_proj.shape[-2:]), threshold=0.007)
             coords = data["coords"].reshape(-1, 2).long()
             mask = mask_full[coords[:, 0], coords[:, 1]]
         else:
             mask = torch.ones(n, dtype=torch.bool, device=self.device)
+        if self.group is not None:                         # global masked mean over all ranks' rays (SURVEY.md 8e)
+            from .dist import global_mean_weights
+            return global_mean_weights(mask, self.group)
         return chunk_mean_weights(mask, 200, self.loss_mode)
 
     def train_step(self, data, global_step, idx_epoch):
@@ -209,7 +234,10 @@ class Trainer:
             rays = data["rays"].reshape(-1, 8).contiguous()
             projs = data["projs"].reshape(-1).float().contiguous()
             weight = self.ray_weights(data, rays.shape[0]).contiguous()
-            loss = self.engine.train_step(rays, projs, weight, ray_base=global_step * rays.shape[0])
+            n = rays.shape[0]
+            loss = self.engine.train_step(rays, projs, weight, ray_base=(global_step * self.world + self.rank) * n)
+            if self.i_log > 0 and global_step % self.i_log == 0:
+                self.writer.add_scalar("train/loss", float(loss), global_step)
             return loss
         self.optimizer.zero_grad()
         loss = self.compute_loss(data, global_step, idx_epoch)

@@ -8,33 +8,40 @@ import torch
 
 
 def get_mse(x, y):
-    if torch.is_complex(x) and torch.is_complex(y):
-        return torch.mean((x.real - y.real) ** 2 + (x.imag - y.imag) ** 2)
-    return torch.mean((x - y) ** 2)
+    """Mean squared error; complex inputs count real and imaginary parts (util.py:18-26)."""
+    diff = x - y
+    if torch.is_complex(diff):
+        return (diff.real.square() + diff.imag.square()).mean()
+    return diff.square().mean()
+
+
+def _unit_range(t):
+    lo, hi = t.min(), t.max()
+    return (t - lo) / (hi - lo)
 
 
 def get_psnr(x, y):
-    x = torch.abs(x)
-    y = torch.abs(y)
-    if torch.max(x) == 0 or torch.max(y) == 0:
+    """PSNR of two projections after each is stretched to [0, 1] on its own (util.py:29-51); 0 if either is all zero."""
+    x, y = x.abs(), y.abs()
+    if x.max() == 0 or y.max() == 0:
         return torch.zeros(1, device=x.device)
-    x_norm = (x - torch.min(x)) / (torch.max(x) - torch.min(x))
-    y_norm = (y - torch.min(y)) / (torch.max(y) - torch.min(y))
-    return -10.0 * torch.log10(get_mse(x_norm, y_norm))
+    return -10.0 * torch.log10(get_mse(_unit_range(x), _unit_range(y)))
+
+
+def _as_volume_batch(a):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a, dtype=np.float64)[np.newaxis]
 
 
 def get_psnr_3d(arr1, arr2, size_average=True, PIXEL_MAX=1.0):
-    if torch.is_tensor(arr1):
-        arr1 = arr1.cpu().detach().numpy()
-    if torch.is_tensor(arr2):
-        arr2 = arr2.cpu().detach().numpy()
-    arr1 = arr1[np.newaxis, ...].astype(np.float64)
-    arr2 = arr2[np.newaxis, ...].astype(np.float64)
-    mse = np.power(arr1 - arr2, 2).mean(axis=1).mean(axis=1).mean(axis=1)
-    zero_mse = np.where(mse == 0)
-    mse[zero_mse] = 1e-10
-    psnr = 20 * np.log10(PIXEL_MAX / np.sqrt(mse))
-    psnr[zero_mse] = 100
+    """Volume PSNR in dB, 20 log10(PIXEL_MAX / rmse) in float64; identical volumes score 100 (util.py:55-84).
+    This is the PSNR of BASELINE.json's +-0.1 dB bar."""
+    a, b = _as_volume_batch(arr1), _as_volume_batch(arr2)
+    mse = np.square(a - b).reshape(a.shape[0], -1).mean(axis=1)
+    psnr = np.full(mse.shape, 100.0)
+    hit = mse > 0
+    psnr[hit] = 20.0 * np.log10(PIXEL_MAX / np.sqrt(mse[hit]))
     return psnr.mean() if size_average else psnr
 
 

@@ -41,10 +41,18 @@ uint32_t naf_oracle_grid_index(uint32_t D, uint32_t C, uint32_t ch, uint32_t has
     return (index % hashmap_size) * C + ch;
 }
 
+/* float -> uint32 as the reference's CUDA build converts (cvt.rzi.u32.f32): saturating, NaN -> 0.  In C the cast is
+ * undefined outside [0, 2^32), so the rule is spelled out. */
+static uint32_t cuda_f2u(float f) {
+    if (!(f > 0.0f)) return 0u;                 /* negative, zero, NaN */
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
 /* hashencoder.cu:99-100 */
 static void level_geometry(uint32_t level, uint32_t H, float *scale, uint32_t *resolution) {
     *scale = exp2f((float)level) * (float)H - 1.0f;
-    *resolution = (uint32_t)ceilf(*scale) + 1u;
+    *resolution = cuda_f2u(ceilf(*scale)) + 1u;
 }
 
 /* hashencoder.cu:106-111 */
@@ -52,7 +60,7 @@ static void locate(uint32_t D, const float *x, float scale, float *frac, uint32_
     for (uint32_t d = 0; d < D; ++d) {
         float p = fmaf(x[d], scale, 0.5f);
         float fl = floorf(p);
-        pg[d] = (uint32_t)fl;
+        pg[d] = cuda_f2u(fl);
         frac[d] = p - (float)pg[d];
     }
 }
@@ -85,15 +93,21 @@ void naf_oracle_hash_encode_forward(const float *inputs, const float *embeddings
         float *out = outputs + ((size_t)level * B + b) * C;
         for (uint32_t c = 0; c < C; ++c) out[c] = acc[c];
 
-        if (calc_grad_inputs) {            /* hashencoder.cu:153-197 (no x scale factor: App. A-3) */
+        if (calc_grad_inputs) {            /* hashencoder.cu:153-197 */
+            /* calc_grad_inputs == 1: the exact derivative, scale * sum_w (right - left) over the corners of the OTHER
+             * dimensions.  == 2: what the reference stores: no scale (:164-165), other dimensions picked
+             * with `nd > gd` (:170) -- for gd < D-1 one coordinate is then never assigned (the CUDA code reads an
+             * uninitialised register); the base corner pg[d] stands in for it. */
+            const int exact = calc_grad_inputs != 2;
             float *dst = dy_dx + ((size_t)b * L + level) * D * C;
             for (uint32_t gd = 0; gd < D; ++gd) {
                 float g[NAF_MAX_C];
                 for (uint32_t c = 0; c < C; ++c) g[c] = 0.0f;
                 for (uint32_t corner = 0; corner < (1u << (D - 1)); ++corner) {
                     float w = 1.0f; uint32_t pl[NAF_MAX_D];
+                    for (uint32_t d = 0; d < D; ++d) pl[d] = pg[d];
                     for (uint32_t nd = 0; nd < D - 1; ++nd) {
-                        const uint32_t d = nd >= gd ? nd + 1 : nd;
+                        const uint32_t d = exact ? (nd >= gd ? nd + 1 : nd) : (nd > gd ? nd + 1 : nd);
                         if ((corner & (1u << nd)) == 0) { w *= 1.0f - frac[d]; pl[d] = pg[d]; }
                         else                             { w *= frac[d];        pl[d] = pg[d] + 1u; }
                     }
@@ -103,7 +117,7 @@ void naf_oracle_hash_encode_forward(const float *inputs, const float *embeddings
                     const uint32_t ir = naf_oracle_grid_index(D, C, 0, hashmap_size, resolution, pl);
                     for (uint32_t c = 0; c < C; ++c) g[c] = fmaf(w, grid[ir + c] - grid[il + c], g[c]);
                 }
-                for (uint32_t c = 0; c < C; ++c) dst[gd * C + c] = g[c];
+                for (uint32_t c = 0; c < C; ++c) dst[gd * C + c] = exact ? g[c] * scale : g[c];
             }
         }
     }

@@ -83,6 +83,32 @@ def geometry_fixture(ref):
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
 
 
+def lamino_chip_fixture(ref):
+    """lamino_chip workload (BASELINE.json configs[2]): the reference's own projection angles (data/angles_real.npy,
+    187 values in degrees, converted like format_data.py:13-14), parallel beam tilted by 29 degrees, 256 x 356 detector
+    (rows x columns, train.py:54).  Rays of three projections from the reference's get_rays2 (the wired path,
+    tigre.py:247,463-528), sub-sampled every 17th row / 19th column to keep the fixture small."""
+    tig = ref["src.dataset.tigre"]
+    angles_deg = np.load(os.path.join(REF, "data", "angles_real.npy"))
+    angles = np.deg2rad(angles_deg.astype(np.float64))
+    data = dict(DSD=1500.0, DSO=1000.0, nDetector=[356, 256], dDetector=[1.0, 1.0], nVoxel=[256, 256, 256],
+                dVoxel=[1.0, 1.0, 1.0], offOrigin=[0, 0, 0], offDetector=[0, 0], accuracy=0.5, mode="parallel", filter=None,
+                tilt_angle=29)
+    geo = tig.ConeGeometry(data)
+    ds = tig.TIGREDataset.__new__(tig.TIGREDataset)
+    ds.geo = geo
+    pick = np.array([0, 93, 186])
+    rays = ds.get_rays2(angles[pick], geo, "cpu", 4).numpy()                # [3, 256, 356, 6]
+    rows, cols = np.arange(0, 256, 17), np.arange(0, 356, 19)
+    out = {"angles_deg": angles_deg, "pick": pick, "rows": rows, "cols": cols,
+           "rays2": rays[:, rows][:, :, cols], "near_far": np.array(ds.get_near_far(geo)),
+           "poses": np.stack([ds.angle2pose(geo.DSO, a, geo.tilt_angle) for a in angles[pick]]), "mode": np.array("parallel")}
+    for k, v in data.items():
+        if k not in ("mode", "filter"):
+            out[f"data/{k}"] = np.asarray(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "lamino_chip.npz"), **out)
+
+
 class _IdentityEncoder(torch.nn.Module):
     """Feeds pre-computed features straight through (lets the reference MLP be pinned on its own)."""
 
@@ -230,10 +256,10 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated in the build container")
     ref = import_reference()
-    geometry_fixture(ref)
-    network_fixture(ref)
-    render_fixture(ref)
-    loss_metrics_fixture(ref)
+    todo = {"geometry": geometry_fixture, "network": network_fixture, "render": render_fixture,
+            "loss_metrics": loss_metrics_fixture, "lamino_chip": lamino_chip_fixture}
+    for name in (sys.argv[1:] or list(todo)):               # optional: names of the fixtures to regenerate
+        todo[name](ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

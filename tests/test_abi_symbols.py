@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_abi.SIGNATURES) == _declared()
-    assert _abi.lib().naf_abi_version() == 1
+    assert _abi.lib().naf_abi_version() == 2
     assert _abi.lib().naf_last_error() is not None
 
 
@@ -47,9 +47,7 @@ def test_argument_validation_needs_no_gpu():
     assert b"C must be 1, 2, 4, or 8" in lib.naf_last_error()
     assert lib.naf_hash_encode_forward(one, one, one, one, 4, 5, 2, 16, 16, 0, None, 0, 0, None) == -2
     assert lib.naf_adam_step(one, one, one, one, None, 0, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0, None) == -1
-    assert lib.naf_set_scatter_mode(7) == -1
-    with pytest.raises(RuntimeError, match="set_scatter_mode"):
-        _abi.check(lib.naf_set_scatter_mode(7), "set_scatter_mode")
+    assert lib.naf_hash_encode_forward(one, one, one, one, 4, 3, 2, 16, 16, 3, one, 0, 0, None) == -1      # calc_grad_inputs in {0,1,2}
     cfg = _abi.RenderCfg(n_samples=192, perturb=1, bound=0.3, L=16, C=2, H=16, table_dtype=2, mlp_precision=2,
                          last_activation=0, seed=0, ray_index_base=0, log2_hashmap_size=19)
     small = lib.naf_render_workspace_bytes(ctypes.byref(cfg), 1000 * 192)
@@ -58,6 +56,15 @@ def test_argument_validation_needs_no_gpu():
     bad = _abi.RenderCfg(n_samples=192, perturb=1, bound=0.3, L=8, C=2, H=16, table_dtype=0, mlp_precision=0,
                          last_activation=0, seed=0, ray_index_base=0, log2_hashmap_size=19)
     assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(bad), one, None) == -2
+    # the scatter mode is part of the cfg (the library keeps no process-wide mode): it sizes the workspace ...
+    atomic = _abi.RenderCfg(n_samples=192, perturb=1, bound=0.3, L=16, C=2, H=16, table_dtype=2, mlp_precision=2,
+                            last_activation=0, seed=0, ray_index_base=0, log2_hashmap_size=19, scatter_mode=_abi.SCATTER_ATOMIC)
+    assert lib.naf_render_workspace_bytes(ctypes.byref(atomic), 16384 * 192) < big
+    # ... and an unknown mode is refused
+    atomic.scatter_mode = 7
+    assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None) == -1
+    with pytest.raises(RuntimeError, match="scatter_mode"):
+        _abi.check(lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None), "render_forward")
 
 
 def test_product_has_no_cpu_fallback():

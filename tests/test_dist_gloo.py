@@ -8,6 +8,8 @@ import torch
 import torch.distributed as td
 import torch.multiprocessing as mp
 
+from _naf_helpers import collect
+
 from neuralvolumetricreconstructionformedicalimages_amd import dist
 
 
@@ -49,7 +51,7 @@ def test_dp_gradients_equal_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = collect(procs, q, len(procs), timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -63,3 +65,47 @@ def test_dp_gradients_equal_single_process():
         np.testing.assert_allclose(loss, float(ref_loss), rtol=1e-5)
         for a, b in zip(grads, ref_grads):
             np.testing.assert_allclose(a, b.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- bucketed exchange: the collectives the engine issues per level bucket ------------------------------------------
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    _, _, _, group = dist.init_from_env(device_type="cpu")
+    from neuralvolumetricreconstructionformedicalimages_amd.encoder import level_offsets
+    offs = level_offsets(3, 16, 16, 14)
+    C = 2
+    n_emb = int(offs[-1]) * C
+    o_mlp = (n_emb + 63) // 64 * 64
+    total = o_mlp + (4225 + 63) // 64 * 64 + 64                     # table | MLP | loss, as engine.NAFEngine lays it out
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(total, generator=g)
+    whole = flat.clone()
+    td.all_reduce(whole, group=group)                               # the single-buffer exchange
+    buckets = dist.default_bucket_levels(16)
+    slices = dist.grad_bucket_slices(offs, C, buckets)
+    dist.all_reduce_buckets_(flat, [(o_mlp, total)] + slices, group)
+    q.put((rank, bool(torch.equal(flat[:n_emb], whole[:n_emb])), bool(torch.equal(flat[o_mlp:], whole[o_mlp:])), slices, buckets))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_bucketed_exchange_equals_single_all_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = collect(procs, q, len(procs), timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, table_ok, mlp_ok, slices, buckets in results:
+        assert table_ok and mlp_ok
+        assert buckets == [(8, 16), (0, 8)]                          # fine levels first: their exchange hides behind the coarse half
+        assert slices[1][0] == 0 and slices[1][1] == slices[0][0]    # the two slices tile the table exactly once
+    with np.testing.assert_raises(ValueError):
+        dist.grad_bucket_slices([0, 10, 20, 30], 2, [(0, 2), (1, 3)])           # overlap
+    with np.testing.assert_raises(ValueError):
+        dist.grad_bucket_slices([0, 10, 20, 30], 2, [(0, 2)])                   # level 2 missing
+    assert dist.grad_bucket_slices([0, 10, 20, 30], 2, [(2, 3), (0, 2)]) == [(40, 60), (0, 40)]

@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from _naf_helpers import collect
+
 pytestmark = pytest.mark.gpu
 
 
@@ -61,7 +63,7 @@ def test_two_rank_training_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    results = sorted(collect(procs, q, len(procs)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -79,6 +81,55 @@ def test_two_rank_training_equals_single_process():
     np.testing.assert_allclose(results[0][2], mlp, rtol=0, atol=2e-4)
     assert np.mean(np.abs(results[0][1] - emb) > 2e-3) < 1e-3
     np.testing.assert_allclose(results[0][3], loss, rtol=1e-3)
+
+
+def _rccl_worker(port, out):
+    """World size 1 over the REAL backend ("nccl" = RCCL): the one-GPU test box cannot host two RCCL ranks, but a
+    single-rank group drives exactly the code the 8-GPU run uses -- bucket events recorded by the library, the side
+    stream waiting on them, ProcessGroupNCCL collectives on slices of the flat buffer, per-bucket Adam."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as td
+    from neuralvolumetricreconstructionformedicalimages_amd import dist
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    rank, world, _, group = 0, 1, 0, None
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    group = td.group.WORLD
+    res = {}
+    for tag, pg, buckets in (("single", None, None), ("dp", group, None), ("dp3", group, [(11, 16), (3, 11), (0, 3)])):
+        net = _make(seed=0)
+        S = 64
+        engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=pg, bucket_levels=buckets)
+        engine.broadcast_parameters()
+        engine.comm_timing(True)
+        rays, t_rand, target, mask = _batch(S=S)
+        for _ in range(3):
+            w = dist.global_mean_weights(mask.cuda(), pg)
+            engine.train_step(rays.cuda(), target.cuda(), w, t_rand=t_rand.cuda())
+        torch.cuda.synchronize()
+        rep = engine.comm_report()
+        res[tag] = (engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item()), rep)
+    out.put(res)
+    td.destroy_process_group()
+
+
+def test_bucketed_rccl_path_with_one_rank_equals_plain_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    res = collect([p], q, 1)[0]
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    emb, mlp, loss, rep = res["single"]
+    assert rep is None
+    for tag in ("dp", "dp3"):
+        e, m, l, r = res[tag]
+        # same records, same integer row sums; only the rare LDS-overflow atomics may reorder
+        np.testing.assert_allclose(m, mlp, rtol=0, atol=1e-6)
+        assert np.mean(np.abs(e - emb) > 1e-6) < 1e-4
+        np.testing.assert_allclose(l, loss, rtol=1e-6)
+        assert r["allreduce_ms_per_step"] >= 0.0 and r["tail_ms_per_step"] > 0.0
 
 
 def test_bench_two_rank_launch_rehearsal():
@@ -104,4 +155,5 @@ def test_bench_two_rank_launch_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 2 * 2048 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert out["allreduce_ms_per_step"] is not None and out["allreduce_bytes"] > 57_000_000
+    assert out["allreduce_exposed_ms_per_step"] is not None and out["allreduce_buckets"] == [[8, 16], [0, 8]]
     assert "cpu_baseline" not in out                               # rank 0 at N = 1 only

@@ -130,6 +130,29 @@ def test_trainer_runs_evaluates_saves_and_resumes(tmp_path, engine):
     assert t2.global_step == 16
 
 
+def test_resume_keeps_the_decayed_learning_rate(tmp_path):
+    """lrate_step smaller than the resume epoch: the decayed rate lives in the optimiser state of the checkpoint and the
+    scheduler must continue from it (torch StepLR's chainable rule, trainer.py:54-66), not snap back to the YAML's lrate."""
+    BasicTrainer = _basic_trainer()
+    data = _scan(n_voxel=16, n_train=2)
+    cfg = _cfg(tmp_path, data, "fused", epochs=3)
+    cfg["train"].update(lrate=4e-3, lrate_gamma=0.5, lrate_step=2)
+    cfg["log"]["i_eval"] = 0
+    t = BasicTrainer(copy.deepcopy(cfg), torch.device("cuda"))
+    t.start()                                              # epochs 0..3 -> four scheduler steps -> two decays
+    assert abs(t.engine.lr - 4e-3 * 0.5 ** 2) < 1e-12
+    ckpt = torch.load(t.ckptdir, weights_only=False)
+    assert abs(ckpt["optimizer"]["param_groups"][0]["lr"] - 2e-3) < 1e-12         # saved before the last scheduler step
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["train"].update(resume=True, epoch=5)
+    t2 = BasicTrainer(cfg2, torch.device("cuda"))
+    assert t2.epoch_start == 4 and abs(t2.engine.lr - 2e-3) < 1e-12              # the checkpoint's rate, not 4e-3
+    t2.lr_scheduler.step()
+    assert abs(t2.engine.lr - 2e-3) < 1e-12                # one step after resume: no snap-back to the config value
+    t2.lr_scheduler.step()
+    assert abs(t2.engine.lr - 1e-3) < 1e-12                # the scheduler's own counter restarts, like the reference's
+
+
 def test_reference_style_state_dict_loads_into_our_module():
     """A checkpoint with the reference's key layout (trainer.py:118-126) loads unchanged."""
     net, ref = _pair(seed=3)

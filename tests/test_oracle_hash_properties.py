@@ -94,11 +94,13 @@ def test_range_check_raises():
     raise AssertionError("expected ValueError (hashgrid.py:122-123)")
 
 
-def test_dy_dx_is_derivative_up_to_scale():
-    # our dy_dx follows the reference layout [B,L,D,C] and, like it, omits the x scale factor (App. A-3)
+def test_dy_dx_exact_mode_is_the_derivative_and_reference_mode_is_the_documented_defect():
+    # dy_dx has the reference layout [B,L,D,C].  calc_grad_inputs=1 is the true derivative (level scale included);
+    # calc_grad_inputs=2 restates what the reference stores: no scale, `nd > gd` dimension pick.
     offs, emb, rng = _setup(L=3)
     x = rng.random((50, 3)).astype(np.float32) * 0.8 + 0.1
-    _, j = c_oracle.hash_encode_forward(x, emb, offs, 4, calc_grad_inputs=True)
+    _, j = c_oracle.hash_encode_forward(x, emb, offs, 4, calc_grad_inputs=1)
+    _, jr = c_oracle.hash_encode_forward(x, emb, offs, 4, calc_grad_inputs=2)
     eps = 1e-3
     for d in range(3):
         xp, xm = x.copy(), x.copy()
@@ -108,6 +110,12 @@ def test_dy_dx_is_derivative_up_to_scale():
         fm = hr.hash_encode_forward(xm, emb, offs, 4).reshape(50, 3, 2)
         for lvl in range(1):                       # level 0: cell size 1/3 >> eps, few points cross a cell
             scale = 2.0 ** lvl * 4 - 1
-            fd = (fp[:, lvl] - fm[:, lvl]) / (2 * eps) / scale
-            ok = np.abs(fd - j[:, lvl, d]) < 5e-2
+            fd = (fp[:, lvl] - fm[:, lvl]) / (2 * eps)
+            ok = np.abs(fd - j[:, lvl, d]) < 5e-2 * scale
             assert ok.mean() > 0.95
+    for lvl in range(3):
+        scale = np.float32(2.0 ** lvl * 4 - 1)
+        # the last dimension picks the right corners in the reference too: only the scale is missing
+        np.testing.assert_allclose(jr[:, lvl, 2] * scale, j[:, lvl, 2], rtol=1e-6, atol=1e-7)
+        # the other two do not (dimension gd itself is used as an interpolation dimension, one is never set)
+        assert not np.allclose(jr[:, lvl, 0] * scale, j[:, lvl, 0], rtol=1e-3, atol=1e-6)

@@ -26,6 +26,6 @@ for r in 128 1024 4096 16384 65536 262144 1048576; do
 done
 echo sweep done
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
-NAF_PROFILE_LEVELS=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
+timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
 echo all done
 find $OUT -name "*.csv" | head -20

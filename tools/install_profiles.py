@@ -10,7 +10,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
 DST = os.path.join(REPO, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "round1"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "round2"
 
 
 def copy(src, dst):
@@ -37,7 +37,12 @@ def hbm(kernel):   # MI355X_MICROARCH.md: value * 1024 (done by pmc_summary), FE
     return 2.0 * row.get("FETCH_SIZE", 0.0) + row.get("WRITE_SIZE", 0.0)
 
 
+sys.path.insert(0, REPO)
+from neuralvolumetricreconstructionformedicalimages_amd.build import source_fingerprint  # noqa: E402
+
 traffic = {
+    "csrc_fingerprint": source_fingerprint(),      # bench.py prints these figures only while the kernel sources are unchanged
+    "collected_at_commit": subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "_comment": "HBM-side bytes per training step (65536 rays, 12.58 M points) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                 "(separate runs), value*1024, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; per-dispatch "
                 f"figures in profiles/{TAG}_pmc_bytes_per_dispatch.json, calibration notes in DESIGN.md section 5",

@@ -95,4 +95,7 @@ if __name__ == "__main__":
     cfg = load_config(args.config)
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X: the NAF hot path has no CPU fallback")
-    BasicTrainer(cfg, torch.device("cuda")).start()
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N train.py --config ...`
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    BasicTrainer(cfg, torch.device("cuda", local_rank)).start()
