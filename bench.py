@@ -110,31 +110,30 @@ def cpu_baseline(seconds, seed=0):
 
 class ScanSampler:
     """The data side of a step on the device (tigre.py:354-372): distinct valid pixels of the step's projections, their
-    measured values, no host synchronisation.  Valid-pixel lists are found once per projection (the reference recomputes
-    `projs[index] > 0` for every item)."""
+    measured values and their rays from ONE launch of `naf_draw_scan_rays`, no host synchronisation.  Valid-pixel lists
+    are found once per projection (the reference recomputes `projs[index] > 0` for every item)."""
 
-    def __init__(self, projs, pixels_per_projection, generator):
-        self.projs = projs                                # [n_proj * H * W] fp32, resident
-        self.hw = pixels_per_projection
-        self.gen = generator
-        self.n_proj = projs.numel() // pixels_per_projection
-        self.valid = []
-        for i in range(self.n_proj):
-            flat = projs[i * self.hw:(i + 1) * self.hw]
-            self.valid.append(torch.nonzero(flat > 0, as_tuple=False).reshape(-1) + i * self.hw)
+    def __init__(self, raygen, projs, seed):
+        self.raygen, self.projs, self.seed = raygen, projs, int(seed)       # projs: [n_proj * H * W] fp32, resident
+        hw = raygen.pixels_per_projection
+        self.n_proj = projs.numel() // hw
+        self.valid = [(torch.nonzero(projs[i * hw:(i + 1) * hw] > 0, as_tuple=False).reshape(-1) + i * hw).contiguous()
+                      for i in range(self.n_proj)]
 
-    def draw(self, step, n):
+    def draw(self, step, n, rays_out):
         per = min(n, RAYS_PER_PROJECTION)
         k = (n + per - 1) // per
-        parts = []
-        for j in range(k):
-            valid = self.valid[(step * k + j) % self.n_proj]
-            m = min(per, n - j * per)
-            if valid.numel() < m:
-                raise ValueError("Cannot take a larger sample than population when 'replace=False'")
-            parts.append(valid[torch.randperm(valid.numel(), device=valid.device, generator=self.gen)[:m]])
-        pixels = parts[0] if k == 1 else torch.cat(parts)
-        return pixels, self.projs[pixels]
+        if k * per != n:
+            raise ValueError(f"--rays must be <= {RAYS_PER_PROJECTION} or a multiple of it")
+        lists = [self.valid[(step * k + j) % self.n_proj] for j in range(k)]
+        seed = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        targets = []
+        for g0 in range(0, k, 16):                          # one launch per 16 projections (65 536 rays: one launch)
+            part = lists[g0:g0 + 16]
+            _, t, _ = self.raygen.draw(part, per, (seed + g0) & (2 ** 64 - 1), projections=self.projs,
+                                       rays_out=rays_out[g0 * per:(g0 + len(part)) * per], want_pixels=False)
+            targets.append(t)
+        return (targets[0] if len(targets) == 1 else torch.cat(targets)), rays_out
 
 
 def main():
@@ -209,7 +208,7 @@ def main():
         r = raygen.rays_for_projection(i)
         for j in range(0, hw, 1 << 16):
             projs[i * hw + j:i * hw + j + (1 << 16)] = phantom.line_integrals(r[j:j + (1 << 16)], table)
-    sampler = ScanSampler(projs, hw, torch.Generator(device=device).manual_seed(1234 + rank))      # each rank draws its own shard
+    sampler = ScanSampler(raygen, projs, 1234 + rank)                 # each rank draws its own shard
     log(f"scan resident: {raygen.n_projections} projections, {min(v.numel() for v in sampler.valid)}.."
         f"{max(v.numel() for v in sampler.valid)} valid pixels each")
 
@@ -236,8 +235,8 @@ def main():
     weight = torch.full((n,), 1.0 / (n * world), device=device)       # global mean over all ranks' rays
 
     def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
-        pixels, target = sampler.draw(i, n_rays)                      # G6: valid-pixel sampling + target gather, on the device
-        raygen.rays_for_pixels(pixels, out=ray_buf)                   # G3: on-the-fly cone-beam ray generation
+        # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip)
+        target, _ = sampler.draw(i, n_rays, ray_buf)
         return (eng or engine).train_step(ray_buf, target, w, ray_base=(i * world + rank) * n_rays)
 
     def barrier():

@@ -96,6 +96,20 @@ int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float
                     uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,
                     void *stream);
 
+/* R5  coarse -> fine resampling in one pass (replaces raw2outputs' weights + sample_pdf + sort, render.py:113-126,203-247):
+ *   sigma        f32 [n_rays, S]        coarse network output per sample (naf_render_forward_samples)
+ *   t_rand       as in naf_sample_rays: the jitter the COARSE pass used (its depths are recomputed here)
+ *   u            f32 [n_rays, n_fine]   uniforms of the inverse-transform sampling, NULL with det != 0 (evenly spaced
+ *                                       quantiles, render.py:228) or to use the counter-based generator
+ *   z_out        f32 [n_rays, S+n_fine] the coarse depths and the new samples, sorted ascending (render.py:123)
+ *   weights_out  f32 [n_rays, S]        optional: the normalised weights ("weights0" of the render dict); the division is by
+ *                                       the maximum over the WHOLE call, like the reference's chunk
+ *   scratch      >= 4 bytes of device memory
+ * One wave per ray: the cdf is an inclusive wave prefix sum, the merge a bitonic sort in LDS.  S <= 1024, S + n_fine <= 2048. */
+int naf_fine_depths(const float *rays, const float *t_rand, const float *sigma, const float *u, float *z_out, float *weights_out,
+                    uint32_t n_rays, uint32_t n_samples, uint32_t n_fine, int perturb, int det, uint64_t seed,
+                    uint32_t ray_index_base, void *scratch, void *stream);
+
 /* G3/G4  ray generation (replaces the precomputed rays[N,H,W,8] of tigre.py:247-255,402-456,463-528)
  *   poses   f32 [n_projections, 3, 4]  = [R | t] of angle2pose (tigre.py:530-572), cast to fp32 like torch.Tensor(pose)
  *   pixels  i64 [n] flat pixel index  proj*H*W + row*W + col, or NULL for the dense range first_pixel .. first_pixel+n-1
@@ -104,6 +118,28 @@ int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float
 int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,
                       uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov,
                       float DSD, float near, float far, int parallel, void *stream);
+
+/* G6  the data side of a training step (replaces np.random.choice(..., replace=False) + the fancy-indexing gathers of
+ * TIGREDataset.__getitem__, tigre.py:354-372): for each of `n_segments` projections, `rays_per_segment` DISTINCT entries of
+ * its list of valid pixels (flat indices proj*H*W + row*W + col whose measured value is non-zero) are drawn uniformly at
+ * random through a keyed bijection of [0, n_valid) -- draw index i -> valid[perm_seed(i)] -- then the measured value is
+ * gathered and the ray generated, all in one launch and without any host round trip.
+ *   pixels  i64 [n_draws] out, optional      target  f32 [n_draws] out, optional (= projections[pixel])
+ *   rays    f32 [n_draws, 8] out
+ * [first_draw, first_draw + n_draws) is a slice of the n_segments * rays_per_segment draws (segment-major): ranks of a
+ * data-parallel job that pass the same seed each take their slice of ONE draw.  A list shorter than rays_per_segment is
+ * refused with the reference's message ("Cannot take a larger sample than population when 'replace=False'"). */
+#define NAF_MAX_DRAW_SEGMENTS 16
+typedef struct naf_scan_draw {
+    uint32_t n_segments;
+    uint32_t rays_per_segment;
+    const int64_t *valid[NAF_MAX_DRAW_SEGMENTS];   /* device pointers */
+    uint32_t n_valid[NAF_MAX_DRAW_SEGMENTS];
+} naf_scan_draw;
+int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses, const float *projections, int64_t *pixels, float *target,
+                       float *rays, uint32_t first_draw, uint32_t n_draws, uint32_t n_projections, uint32_t det_w, uint32_t det_h,
+                       float du, float dv, float ou, float ov, float DSD, float near, float far, int parallel, uint64_t seed,
+                       void *stream);
 
 /* R4  line integral acc = sum_s sigma_s * dist_s  (render.py:192-201), and its backward.
  *   sigma f32 [n_rays, S]; z_vals f32 [n_rays, S]; rays f32 [n_rays, 8]; acc f32 [n_rays]
@@ -146,6 +182,9 @@ typedef struct naf_render_cfg {
 
 #define NAF_CFG_PER_LEVEL_LAUNCHES 1u /* diagnostics: one launch per level instead of level-major grids, so that
                                          naf_profile_collect() reports per-level times (changes the workspace size) */
+#define NAF_CFG_EXPLICIT_DEPTHS 2u    /* the `t_rand` argument of the naf_render_* entry points holds the sample DEPTHS
+                                         z[n_rays, S] themselves (the fine pass renders at the merged, sorted depths of
+                                         naf_fine_depths, render.py:123-126); `perturb` is ignored                    */
 
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */

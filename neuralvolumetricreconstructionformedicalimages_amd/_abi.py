@@ -18,6 +18,7 @@ LAYOUT_LBC, LAYOUT_BLC = 0, 1
 MLP_PARAMS = 4225
 SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED = 0, 1, 2
 CFG_PER_LEVEL_LAUNCHES = 1
+CFG_EXPLICIT_DEPTHS = 2
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -47,6 +48,17 @@ class GradBuckets(ctypes.Structure):
     ]
 
 
+MAX_DRAW_SEGMENTS = 16
+
+
+class ScanDraw(ctypes.Structure):
+    """struct naf_scan_draw (include/naf_hip.h): valid-pixel lists of the projections a step draws from."""
+    _fields_ = [
+        ("n_segments", ctypes.c_uint32), ("rays_per_segment", ctypes.c_uint32),
+        ("valid", ctypes.c_void_p * MAX_DRAW_SEGMENTS), ("n_valid", ctypes.c_uint32 * MAX_DRAW_SEGMENTS),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/naf_hip.h one to one (checked by tests/test_abi_symbols.py)
 _vp, _u32, _u64, _i32, _f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
@@ -57,6 +69,9 @@ SIGNATURES = {
     "naf_hash_encode_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _i32, _i32, _vp]),
     "naf_hash_encode_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "naf_sample_rays": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _f32, _u64, _u32, _vp]),
+    "naf_fine_depths": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _u64, _u32, _vp, _vp]),
+    "naf_draw_scan_rays": (_i32, [ctypes.POINTER(ScanDraw), _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32,
+                                  _f32, _f32, _f32, _i32, _u64, _vp]),
     "naf_generate_rays": (_i32, [_vp, _vp, ctypes.c_int64, _vp, _u64, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "naf_integrate_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "naf_integrate_backward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),

@@ -61,6 +61,7 @@ struct SrcRays {
     const float *__restrict__ t_rand;  // [n_rays, S] or nullptr
     uint32_t S;
     bool perturb;
+    bool explicit_z;                   // t_rand holds the depths themselves (NAF_CFG_EXPLICIT_DEPTHS: the fine pass)
     float bound;
     uint64_t seed;
     uint32_t ray_base;
@@ -81,6 +82,7 @@ struct SrcRays {
         return near * (1.0f - t) + far * t;
     }
     __device__ __forceinline__ float depth(uint32_t r, uint32_t s, float near, float far) const {
+        if (explicit_z) return t_rand[(size_t)r * S + s];                  // wave-uniform branch
         const float z = base(near, far, s);
         if (!perturb) return z;
         const float u = t_rand ? t_rand[(size_t)r * S + s] : jitter(seed, ray_base + r, s);

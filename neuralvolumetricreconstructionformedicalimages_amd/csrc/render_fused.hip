@@ -824,6 +824,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -958,7 +959,8 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
 
 template <typename P, uint32_t C, typename Rec, uint32_t NT>
 static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                                 const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
+                                 const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
+                                 const naf_grad_buckets *buckets, hipStream_t s) {
     using FT = typename P::feat_t;
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
     // position is evaluated once per point, and stores drain behind the next level: 3.85 -> 3.53 ms at 65 536 rays),
@@ -974,48 +976,71 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
     const uint32_t bin_lds = 2u * NB * 4u + NB * plan.slot_cap * (uint32_t)sizeof(Rec);
     if (int rc = raise_lds_limit(red, red_lds, "binned scatter: cannot raise dynamic LDS limit (reduce)")) return rc;
     if (int rc = raise_lds_limit(bin, bin_lds, "binned scatter: cannot raise dynamic LDS limit (bin)")) return rc;
+    static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
+    static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
+    const bool per_level = per_level_launches(cfg);
+    // pass 1 over the levels [l0, l0 + nl): their records fill the region buffer from level slot 0
+    auto launch_bin = [&](uint32_t l0, uint32_t nl) -> int {
+        ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
+        hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(NT), bin_lds, s, src, (const typename FT::store_t *)dfeat,
+                           offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan);
+        return check_launch("scatter_bin_kernel");
+    };
+    // passes 2 + 3 over the level slots [ly0, ly0 + nl) of a bin pass that started at level l0
+    auto launch_reduce = [&](uint32_t l0, uint32_t ly0, uint32_t nl) -> int {
+        ProfScope prof_(per_level ? level_name(red_names, l0 + ly0) : "scatter_reduce_kernel", s);
+        // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles.
+        // (A reducer workgroup owns a CU's LDS, so 256 run at a time: 512 or more unsplit ones already come in full rounds.)
+        const uint32_t n_split = NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl)));
+        hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
+                           grad_table, w.sums, w.gmax, cfg->H, l0, ly0, plan);
+        if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
+            hipLaunchKernelGGL((scatter_apply_kernel<C>), dim3((plan.max_local_rows + 63u) / 64u, nl, NB / 64u), dim3(256), 0, s,
+                               w.sums, offsets, grad_table, cfg->H, l0, ly0, plan);
+        return check_launch("scatter_reduce_kernel");
+    };
+    if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {
+        // data parallel, and the records of all levels fit one pass: bin ONCE (the sample position is evaluated once per
+        // point and the stores of a level drain behind the next, exactly as in the single-GPU step), then finish the table
+        // bucket by bucket -- each bucket's event fires as soon as its rows are final, and its all-reduce overlaps the
+        // reduction of the buckets that follow.
+        if (int rc = launch_bin(0u, cfg->L)) return rc;
+        for (uint32_t b = 0; b < buckets->n_buckets; ++b) {
+            if (int rc = launch_reduce(0u, buckets->level_begin[b], buckets->level_end[b] - buckets->level_begin[b])) return rc;
+            if (buckets->ready[b] != nullptr && hipEventRecord((hipEvent_t)buckets->ready[b], s) != hipSuccess)
+                return fail(NAF_ERR_LAUNCH, "render_train: cannot record a bucket event");
+        }
+        return NAF_OK;
+    }
     for (uint32_t l0 = lv_begin; l0 < lv_end; l0 += plan.levels_per_pass) {
         const uint32_t nl = std::min(plan.levels_per_pass, lv_end - l0);
-        static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
-        static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
-        const bool per_level = per_level_launches(cfg);
-        { ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
-          hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(NT), bin_lds, s, src, (const typename FT::store_t *)dfeat,
-                             offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan); }
-        if (int rc = check_launch("scatter_bin_kernel")) return rc;
-        { ProfScope prof_(per_level ? level_name(red_names, l0) : "scatter_reduce_kernel", s);
-          // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles.
-          // (A reducer workgroup owns a CU's LDS, so 256 run at a time: 512 or more unsplit ones already come in full rounds.)
-          const uint32_t n_split = NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl)));
-          hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                             grad_table, w.sums, w.gmax, cfg->H, l0, plan);
-          if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
-              hipLaunchKernelGGL((scatter_apply_kernel<C>), dim3((plan.max_local_rows + 63u) / 64u, nl, NB / 64u), dim3(256), 0, s,
-                                 w.sums, offsets, grad_table, cfg->H, l0, plan); }
-        if (int rc = check_launch("scatter_reduce_kernel")) return rc;
+        if (int rc = launch_bin(l0, nl)) return rc;
+        if (int rc = launch_reduce(l0, 0u, nl)) return rc;
     }
     return NAF_OK;
 }
 
 template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                              const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
+                              const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
+                              const naf_grad_buckets *buckets, hipStream_t s) {
     if constexpr (sizeof(Rec) <= 8) {                            // tile size chosen by make_bin_plan
-        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
-        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
+        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
+        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
     } else {
-        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
+        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
     }
 }
 
 // Table-gradient scatter of the levels [lv_begin, lv_end).
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                                    const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
+                                    const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
+                                    const naf_grad_buckets *buckets = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
-        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, s);
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
+        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
     }
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("hash_backward_kernel_L");
@@ -1039,6 +1064,8 @@ static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s) {
     if (w.binned && hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
     if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s);
+    if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
+        return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
     for (uint32_t b = 0; b < buckets->n_buckets; ++b) {
         if (int rc = run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, buckets->level_begin[b], buckets->level_end[b], s)) return rc;
         if (buckets->ready[b] != nullptr && hipEventRecord((hipEvent_t)buckets->ready[b], s) != hipSuccess)
@@ -1050,6 +1077,7 @@ static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_
 static SrcRays make_src(const float *rays, const float *t_rand, const naf_render_cfg *cfg) {
     SrcRays s;
     s.rays = rays; s.t_rand = t_rand; s.S = cfg->n_samples; s.perturb = cfg->perturb != 0; s.bound = cfg->bound;
+    s.explicit_z = (cfg->flags & NAF_CFG_EXPLICIT_DEPTHS) != 0u;
     s.seed = cfg->seed; s.ray_base = cfg->ray_index_base;
     s.div_magic = (uint32_t)((1ull << 32) / s.S);
     s.lin_step = 1.0f / (float)(s.S - 1u);

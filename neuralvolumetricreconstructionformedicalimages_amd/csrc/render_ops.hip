@@ -1,6 +1,9 @@
 // render_ops.hip -- stand-alone ray-march operators for gfx950: stratified sampling, the attenuation line
 // integral and its backward, the encoder range check.  They back the drop-in `render()` surface
 // (reference src/render/render.py:82-212); the fused training path lives in render_fused.hip.
+#include <cmath>
+#include <cstring>
+
 #include "naf_device.h"
 #include "naf_host.h"
 
@@ -68,6 +71,121 @@ integrate_backward_kernel(const float *__restrict__ grad_acc, const float *__res
         const float *ray = rays + (size_t)r * 8;
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
         grad_sigma[i] = grad_acc[r] * dist_at(z_vals + (size_t)r * S, s, S, dnorm);
+    }
+}
+
+// ---- coarse -> fine resampling (render.py:113-126 + raw2outputs weights :203-206 + sample_pdf :215-247) ----------------
+// The reference runs ~25 ATen kernels per chunk for this (abs/cat/max/div, cumsum, searchsorted, two gathers over an expanded
+// [n, N_fine, S] view, where, sort of the concatenation).  Here: one small pass for the chunk-wide maximum of the weights,
+// then ONE wave per ray does everything in LDS -- coarse depths, interval weights, their inclusive WAVE PREFIX SUM (the
+// cdf), inverse-transform sampling by binary search, and a bitonic sort of the merged depths.
+
+// weights = |sigma[s] - sigma[s-1]| (1e-10 for the first sample); max over the whole chunk as the bit pattern of a
+// non-negative float (orders like an unsigned integer).  The caller initialises *max_bits with the bits of 1e-10f.
+__global__ void __launch_bounds__(256)
+fine_weight_max_kernel(const float *__restrict__ sigma, uint64_t total, uint32_t S, uint32_t *__restrict__ max_bits) {
+    float m = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(i % S);
+        if (s != 0u) m = fmaxf(m, fabsf(sigma[i] - sigma[i - 1]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63u) == 0u && m > 0.0f) atomicMax(max_bits, __float_as_uint(m));
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS per wave: z[S] | cdf[S-1 (+1)] | merged[P], P = power of two >= S + N_fine.
+__global__ void __launch_bounds__(256)
+fine_depths_kernel(const float *__restrict__ rays, const float *__restrict__ t_rand, const float *__restrict__ sigma,
+                   const uint32_t *__restrict__ max_bits, const float *__restrict__ u_rand, float *__restrict__ z_out,
+                   float *__restrict__ weights_out, uint32_t n_rays, uint32_t S, uint32_t NF, uint32_t P, bool perturb, bool det,
+                   uint64_t seed, uint32_t ray_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    float *zc = reinterpret_cast<float *>(smem) + (size_t)wib * (2u * S + P);
+    float *cdf = zc + S;                                    // S - 1 entries: one per bin edge (mid-point of two samples)
+    float *merged = cdf + S;
+    const float wmax = __uint_as_float(*max_bits);
+    const uint32_t M = S - 1u;                              // bin edges; M - 1 = S - 2 intervals carry the weights 1 .. S-2
+    for (uint32_t r = wave; r < n_rays; r += n_waves) {
+        const float *ray = rays + (size_t)r * 8;
+        const float near = ray[6], far = ray[7];
+        for (uint32_t s = lane; s < S; s += 64u) {
+            float uu = 0.0f;
+            if (perturb) uu = t_rand ? t_rand[(size_t)r * S + s] : jitter(seed, ray_base + r, s);
+            const float z = sample_z(near, far, s, S, perturb, uu);
+            zc[s] = z;
+            merged[s] = z;
+        }
+        // interval weights (+1e-5, render.py:217) and their sum
+        const float *sg = sigma + (size_t)r * S;
+        float part = 0.0f;
+        for (uint32_t s = lane; s < S; s += 64u) {
+            const float w = s == 0u ? 1e-10f / wmax : fabsf(sg[s] - sg[s - 1u]) / wmax;
+            if (weights_out) weights_out[(size_t)r * S + s] = w;
+            if (s >= 1u && s + 1u < S) part += w + 1e-5f;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float total = part;
+        // cdf[k] = sum_{i < k} pdf[i], pdf[i] = (w[i+1] + 1e-5) / total: inclusive wave prefix sum, 64 intervals at a time
+        float carry = 0.0f;
+        if (lane == 0u) cdf[0] = 0.0f;
+        for (uint32_t base = 0; base + 1u < M; base += 64u) {
+            const uint32_t i = base + lane;                 // interval index, < M - 1
+            const bool in = i + 1u < M;
+            float v = in ? (fabsf(sg[i + 1u] - sg[i]) / wmax + 1e-5f) / total : 0.0f;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const float up = __shfl_up(v, d, 64);
+                if (lane >= d) v += up;
+            }
+            v += carry;
+            if (in) cdf[i + 1u] = v;
+            carry = __shfl(v, 63, 64);
+        }
+        wave_lds_sync();
+        // inverse-transform samples
+        for (uint32_t j = lane; j < NF; j += 64u) {
+            float uq;
+            if (det) uq = lin_t(j, NF);                      // torch.linspace(0, 1, N_fine)
+            else uq = u_rand ? u_rand[(size_t)r * NF + j] : jitter(seed ^ 0x9e3779b97f4a7c15ull, ray_base + r, j);
+            uint32_t lo = 0u, hi = M;                        // searchsorted(cdf, u, right=True): entries <= u
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cdf[mid] <= uq) lo = mid + 1u; else hi = mid;
+            }
+            const uint32_t below = lo == 0u ? 0u : lo - 1u, above = lo < M ? lo : M - 1u;
+            const float c0 = cdf[below], c1 = cdf[above];
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uq - c0) / denom;
+            const float b0 = 0.5f * (zc[below + 1u] + zc[below]), b1 = 0.5f * (zc[above + 1u] + zc[above]);
+            merged[S + j] = b0 + t * (b1 - b0);
+        }
+        for (uint32_t i = S + NF + lane; i < P; i += 64u) merged[i] = INFINITY;
+        wave_lds_sync();
+        // bitonic sort of merged[0, P), ascending
+        for (uint32_t k = 2u; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                for (uint32_t t = lane; t < (P >> 1); t += 64u) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i | j;     // the pair (i, i + j)
+                    const float a = merged[i], b = merged[q];
+                    const bool up = (i & k) == 0u;
+                    if ((a > b) == up) { merged[i] = b; merged[q] = a; }
+                }
+                wave_lds_sync();
+            }
+        }
+        for (uint32_t i = lane; i < S + NF; i += 64u) z_out[(size_t)r * (S + NF) + i] = merged[i];
+        wave_lds_sync();
     }
 }
 
@@ -141,6 +259,33 @@ extern "C" int naf_integrate_backward(const float *grad_acc, const float *z_vals
     return check_launch("integrate_backward_kernel");
 }
 
+extern "C" int naf_fine_depths(const float *rays, const float *t_rand, const float *sigma, const float *u, float *z_out,
+                               float *weights_out, uint32_t n_rays, uint32_t n_samples, uint32_t n_fine, int perturb, int det,
+                               uint64_t seed, uint32_t ray_index_base, void *scratch, void *stream) {
+    if (!rays || !sigma || !z_out || !scratch) return fail(NAF_ERR_INVALID_ARGUMENT, "fine_depths: null pointer");
+    if (n_samples < 3 || n_fine == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "fine_depths: needs n_samples >= 3 and n_fine >= 1");
+    if (n_samples > 1024u || n_samples + n_fine > 2048u)
+        return fail(NAF_ERR_UNSUPPORTED, "fine_depths: at most 1024 coarse and 2048 merged depths per ray (LDS-resident sort)");
+    if (n_rays == 0) return NAF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float floor_w = 1e-10f;                            // the first sample's weight (render.py:204) bounds the maximum from below
+    uint32_t bits;
+    std::memcpy(&bits, &floor_w, 4);
+    if (hipMemsetD32Async((hipDeviceptr_t)scratch, (int)bits, 1, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "fine_depths: memset failed");
+    const uint64_t total = (uint64_t)n_rays * n_samples;
+    { ProfScope prof_("fine_weight_max_kernel", s); hipLaunchKernelGGL(fine_weight_max_kernel, dim3(grid_for(total, 1024, 1024)), dim3(256), 0, s, sigma, total, n_samples, (uint32_t *)scratch); }
+    if (int rc = check_launch("fine_weight_max_kernel")) return rc;
+    uint32_t P = 2;
+    while (P < n_samples + n_fine) P <<= 1;
+    const uint32_t lds = 4u * (2u * n_samples + P) * 4u;
+    if (lds > (64u << 10) &&
+        hipFuncSetAttribute((const void *)fine_depths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(NAF_ERR_LAUNCH, "fine_depths: cannot raise dynamic LDS limit");
+    { ProfScope prof_("fine_depths_kernel", s); hipLaunchKernelGGL(fine_depths_kernel, dim3(grid_for(n_rays, 4)), dim3(256), lds, s, rays, t_rand, sigma, (const uint32_t *)scratch, u, z_out,
+                       weights_out, n_rays, n_samples, n_fine, P, perturb != 0, det != 0, seed, ray_index_base); }
+    return check_launch("fine_depths_kernel");
+}
+
 extern "C" int naf_normalize_inputs(const float *x, uint64_t n, float size, float *out01, int32_t *flag, void *stream) {
     if (!x || !flag) return fail(NAF_ERR_INVALID_ARGUMENT, "normalize_inputs: null pointer");
     if (n == 0) return NAF_OK;
@@ -163,41 +308,124 @@ struct RayGeo {
     int parallel;           // 0 cone, 1 parallel
 };
 
+__device__ __forceinline__ void make_ray(const float *__restrict__ poses, uint64_t flat, const RayGeo &g, float4 *out) {
+    const uint64_t per_proj = (uint64_t)g.W * g.H;
+    const uint32_t proj = (uint32_t)(flat / per_proj);
+    const uint32_t rem = (uint32_t)(flat - (uint64_t)proj * per_proj);
+    const uint32_t row = rem / g.W, col = rem - row * g.W;
+    const float *P = poses + (size_t)proj * 12;                 // 3x4 row-major [R | t]
+    // tigre.py:423-429: uu along columns, vv along rows
+    const float uu = ((float)col + 0.5f - (float)g.W / 2.0f) * g.du + g.ou;
+    const float vv = ((float)row + 0.5f - (float)g.H / 2.0f) * g.dv + g.ov;
+    float o[3], d[3];
+    if (!g.parallel) {                                          // tigre.py:434-437
+        const float dx = uu / g.DSD, dy = vv / g.DSD;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[k] = P[4 * k + 0] * dx + P[4 * k + 1] * dy + P[4 * k + 2];
+            o[k] = P[4 * k + 3];
+        }
+    } else {                                                    // tigre.py:438-447
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[k] = P[4 * k + 2];
+            o[k] = P[4 * k + 0] * uu + P[4 * k + 1] * vv + P[4 * k + 3];
+        }
+    }
+    out[0] = make_float4(o[0], o[1], o[2], d[0]);
+    out[1] = make_float4(d[1], d[2], g.near, g.far);
+}
+
 __global__ void __launch_bounds__(256)
 generate_rays_kernel(const float *__restrict__ poses, const int64_t *__restrict__ pixels, int64_t first_pixel,
                      float *__restrict__ rays, uint64_t n, RayGeo g) {
-    const uint64_t per_proj = (uint64_t)g.W * g.H;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t flat = pixels ? (uint64_t)pixels[i] : (uint64_t)first_pixel + i;
-        const uint32_t proj = (uint32_t)(flat / per_proj);
-        const uint32_t rem = (uint32_t)(flat - (uint64_t)proj * per_proj);
-        const uint32_t row = rem / g.W, col = rem - row * g.W;
-        const float *P = poses + (size_t)proj * 12;                 // 3x4 row-major [R | t]
-        // tigre.py:423-429: uu along columns, vv along rows
-        const float uu = ((float)col + 0.5f - (float)g.W / 2.0f) * g.du + g.ou;
-        const float vv = ((float)row + 0.5f - (float)g.H / 2.0f) * g.dv + g.ov;
-        float o[3], d[3];
-        if (!g.parallel) {                                          // tigre.py:434-437
-            const float dx = uu / g.DSD, dy = vv / g.DSD;
+        make_ray(poses, flat, g, reinterpret_cast<float4 *>(rays + i * 8));
+    }
+}
+
+// ---- G6: the data side of a training step on the device (reference src/dataset/tigre.py:354-372) ------------------
+// `np.random.choice(valid, n_rays, replace=False)` + three fancy-indexing gathers per item become ONE launch: draw index i
+// is sent through a keyed bijection of [0, n_valid) (a 4-round Feistel network on the smallest even-width bit field that
+// covers n_valid, restricted to the range by cycle walking), so the first n outputs are n DISTINCT uniformly chosen
+// entries of the valid-pixel list -- no sort, no host synchronisation, and ranks of a data-parallel job that share the
+// seed can each take a slice of the same draw.  The thread then gathers the measured value and generates the ray.
+struct ScanDraw {
+    uint32_t n_segments, per_segment;
+    const int64_t *valid[NAF_MAX_DRAW_SEGMENTS];
+    uint32_t n_valid[NAF_MAX_DRAW_SEGMENTS];
+};
+
+__device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_t n, uint32_t half_bits, uint64_t seed) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t x = i;
+    do {                                                     // the walk stays inside the cycle of i: still a bijection on [0, n)
+        uint32_t l = x >> half_bits, r = x & mask;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d[k] = P[4 * k + 0] * dx + P[4 * k + 1] * dy + P[4 * k + 2];
-                o[k] = P[4 * k + 3];
-            }
-        } else {                                                    // tigre.py:438-447
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d[k] = P[4 * k + 2];
-                o[k] = P[4 * k + 0] * uu + P[4 * k + 1] * vv + P[4 * k + 3];
-            }
+        for (uint32_t round = 0; round < 4u; ++round) {
+            const uint32_t f = mix32(r ^ (round & 1u ? k1 : k0) ^ (0x9e3779b9u * (round + 1u))) & mask;
+            const uint32_t t = l ^ f;
+            l = r;
+            r = t;
         }
-        float4 *out = reinterpret_cast<float4 *>(rays + i * 8);
-        out[0] = make_float4(o[0], o[1], o[2], d[0]);
-        out[1] = make_float4(d[1], d[2], g.near, g.far);
+        x = (l << half_bits) | r;
+    } while (x >= n);
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+draw_scan_rays_kernel(ScanDraw draw, const float *__restrict__ poses, const float *__restrict__ projections,
+                      int64_t *__restrict__ pixels, float *__restrict__ target, float *__restrict__ rays, uint32_t first,
+                      uint32_t count, RayGeo g, uint64_t seed) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint32_t i = first + t;                           // global draw index: segment-major
+        const uint32_t seg = i / draw.per_segment, k = i - seg * draw.per_segment;
+        const uint32_t n = draw.n_valid[seg];
+        uint32_t half_bits = 1u;
+        while ((1ull << (2u * half_bits)) < (uint64_t)n) ++half_bits;
+        const uint32_t idx = feistel_permute(k, n, half_bits, seed + 0x632be59bd9b4e019ull * (seg + 1u));
+        const int64_t flat = draw.valid[seg][idx];
+        if (pixels) pixels[t] = flat;
+        if (target) target[t] = projections[flat];
+        make_ray(poses, (uint64_t)flat, g, reinterpret_cast<float4 *>(rays + (size_t)t * 8));
     }
 }
 
 }  // namespace naf
+
+extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses, const float *projections, int64_t *pixels,
+                                  float *target, float *rays, uint32_t first_draw, uint32_t n_draws, uint32_t n_projections,
+                                  uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov, float DSD, float near,
+                                  float far, int parallel, uint64_t seed, void *stream) {
+    if (!draw || !poses || !rays) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: null pointer");
+    if (target && !projections) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: target without projections");
+    if (draw->n_segments == 0 || draw->n_segments > NAF_MAX_DRAW_SEGMENTS || draw->rays_per_segment == 0)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: n_segments must be in [1, 16] and rays_per_segment > 0");
+    if (det_w == 0 || det_h == 0 || n_projections == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: empty detector");
+    if (((uintptr_t)rays) & 15u) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: rays must be 16-byte aligned");
+    const uint64_t total = (uint64_t)draw->n_segments * draw->rays_per_segment;
+    if ((uint64_t)first_draw + n_draws > total) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: draw range outside n_segments * rays_per_segment");
+    ScanDraw d;
+    d.n_segments = draw->n_segments;
+    d.per_segment = draw->rays_per_segment;
+    for (uint32_t j = 0; j < NAF_MAX_DRAW_SEGMENTS; ++j) {
+        const bool used = j < draw->n_segments;
+        d.valid[j] = used ? draw->valid[j] : nullptr;
+        d.n_valid[j] = used ? draw->n_valid[j] : 0u;
+        if (used && !draw->valid[j]) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: null valid-pixel list");
+        // the reference's np.random.choice(..., replace=False) raises the same way (tigre.py:357)
+        if (used && draw->n_valid[j] < draw->rays_per_segment)
+            return fail(NAF_ERR_INVALID_ARGUMENT, "Cannot take a larger sample than population when 'replace=False'");
+    }
+    if (n_draws == 0) return NAF_OK;
+    RayGeo g{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
+    { ProfScope prof_("draw_scan_rays_kernel", (hipStream_t)stream);
+      hipLaunchKernelGGL(draw_scan_rays_kernel, dim3(grid_for(n_draws, 256)), dim3(256), 0, (hipStream_t)stream, d, poses, projections,
+                         pixels, target, rays, first_draw, n_draws, g, seed); }
+    return check_launch("draw_scan_rays_kernel");
+}
 
 extern "C" int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,
                                  uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv, float ou,

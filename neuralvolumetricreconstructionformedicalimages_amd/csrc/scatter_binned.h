@@ -308,7 +308,7 @@ template <uint32_t C, typename Rec>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, float *__restrict__ sums, const uint32_t *__restrict__ gmax_bits,
-                      uint32_t H, uint32_t level_base, BinPlan plan) {
+                      uint32_t H, uint32_t level_base, uint32_t ly_begin, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift(gbits);
@@ -316,7 +316,7 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const double scale = ldexp(1.0, shift);
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t T_ = blockDim.x, CAP = plan.slot_cap;
-    const uint32_t bucket = blockIdx.x, ly = blockIdx.y, level = level_base + ly;
+    const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
     const uint32_t full_groups = T >> plan.log2_nb;
@@ -422,9 +422,9 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 template <uint32_t C>
 __global__ void __launch_bounds__(256)
 scatter_apply_kernel(const float *__restrict__ sums, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
-                     uint32_t H, uint32_t level_base, BinPlan plan) {
+                     uint32_t H, uint32_t level_base, uint32_t ly_begin, BinPlan plan) {
     __shared__ float tile[64][64 * C + 1];                      // [bucket in group][local in block][C], odd pitch
-    const uint32_t ly = blockIdx.y, level = level_base + ly, local0 = blockIdx.x * 64u, bucket0 = blockIdx.z * 64u;
+    const uint32_t ly = ly_begin + blockIdx.y, level = level_base + ly, local0 = blockIdx.x * 64u, bucket0 = blockIdx.z * 64u;
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
     if (((size_t)local0 << plan.log2_nb) >= T) return;          // block past the end of this level (uniform)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

@@ -86,6 +86,9 @@ class TIGREDataset(Dataset):
         if seed is not None:
             self._generator = torch.Generator(device=self.device)
             self._generator.manual_seed(int(seed))
+        # keyed draws of naf_draw_scan_rays: (seed, item counter) -> one key per item; unseeded datasets start from entropy
+        self._draw_seed = int(seed) if seed is not None else int(torch.seed() & 0x7FFFFFFFFFFFFFFF)
+        self._draw_count = 0
 
     @property
     def voxels(self):
@@ -97,12 +100,32 @@ class TIGREDataset(Dataset):
         return self.n_samples
 
     def _valid_pixels(self, index):
+        """Pixels of projection `index` with a non-zero measured value (tigre.py:354-356), as indices inside the projection."""
         index = int(index)
         hit = self._valid.get(index)
         if hit is None:
             flat = self.projs[index].reshape(-1)
-            hit = self._valid[index] = torch.nonzero(flat.abs() > 0, as_tuple=False).reshape(-1)
+            hit = self._valid[index] = torch.nonzero(flat.abs() > 0, as_tuple=False).reshape(-1).contiguous()
         return hit
+
+    def draw_item(self, index):
+        """One training item drawn entirely on the device (`naf_draw_scan_rays`): n_rays distinct valid pixels of projection
+        `index`, their measured values and rays in one launch -- no randperm sort, no host synchronisation once the
+        projection's valid list is cached.  With shard = (rank, world) every rank takes its slice of the SAME draw."""
+        index = int(index)
+        key = ("flat", index)
+        valid = self._valid.get(key)
+        if valid is None:
+            valid = self._valid[key] = (self._valid_pixels(index) + index * self.raygen.pixels_per_projection).contiguous()
+        self._draw_count += 1
+        seed = (self._draw_seed * 0x9E3779B97F4A7C15 + self._draw_count * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        first, count = 0, self.n_rays
+        if self.shard[1] > 1:
+            from .dist import shard_range
+            first, end = shard_range(self.n_rays, *self.shard)
+            count = end - first
+        pixels, target, rays = self.raygen.draw([valid], self.n_rays, seed, projections=self.projs.reshape(-1), first=first, count=count)
+        return pixels - index * self.raygen.pixels_per_projection, target, rays
 
     def ptycho_mask(self, index, threshold=0.007):
         """`get_ptycho_mask(full_proj[index])` (util.py:196-205), computed once per projection."""
@@ -127,15 +150,9 @@ class TIGREDataset(Dataset):
 
     def __getitem__(self, index):
         if self.type == "train":
-            pix = self.sample_pixels(index)
-            if self.shard[1] > 1:
-                from .dist import shard_range
-                begin, end = shard_range(pix.numel(), *self.shard)
-                pix = pix[begin:end]
+            pix, projs, rays = self.draw_item(index)
             W = self.raygen.W
             select_coords = torch.stack([pix // W, pix % W], -1)
-            rays = self.raygen.rays_for_pixels(index * self.raygen.pixels_per_projection + pix)
-            projs = self.projs[index].reshape(-1)[pix]
             out = {"projs": projs, "rays": rays, "coords": select_coords}
             if self.full_proj is not None:
                 out["full_proj"] = self.full_proj[index]

@@ -113,10 +113,55 @@ class _FusedRender(Function):
         return None, None, grad_emb.to(emb.dtype), grad_mlp, None, None
 
 
-def fused_render(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_precision=None):
-    """Differentiable fused render of `rays` [n,8] through `net` (a fused_supported() DensityNetwork) -> acc [n]."""
-    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed)
+def fused_render(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_precision=None, z_vals=None):
+    """Differentiable fused render of `rays` [n,8] through `net` (a fused_supported() DensityNetwork) -> acc [n].
+    `z_vals` [n, n_samples]: render at these (sorted) depths instead of the stratified ones -- the fine pass."""
+    flags = None
+    if z_vals is not None:
+        z_vals = z_vals.detach().contiguous().float()      # render.py:121: the fine depths carry no gradient
+        if z_vals.shape != (rays.shape[0], n_samples):
+            raise ValueError("z_vals must be [n_rays, n_samples]")
+        t_rand, perturb, flags = z_vals, False, _default_flags | _abi.CFG_EXPLICIT_DEPTHS
+    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed, flags=flags)
     return _FusedRender.apply(rays, t_rand, net.encoder.embeddings, net.packed_mlp(), _offsets(net.encoder, rays.device), cfg)
+
+
+@torch.no_grad()
+def fine_depths(rays, sigma, n_fine, perturb, t_rand=None, u=None, det=False, seed=0):
+    """Coarse -> fine resampling on the device (naf_fine_depths): `sigma` [n, S] of the coarse pass ->
+    (z_all [n, S + n_fine] sorted, weights0 [n, S]).  `t_rand` is the jitter the coarse pass used; `u` [n, n_fine] the
+    uniforms of the inverse-transform sampling (None with det=True: evenly spaced quantiles)."""
+    rays = rays.contiguous().float()
+    sigma = sigma.contiguous().float()
+    n, S = sigma.shape
+    z_all = torch.empty(n, S + n_fine, device=rays.device, dtype=torch.float32)
+    weights = torch.empty(n, S, device=rays.device, dtype=torch.float32)
+    scratch = torch.empty(1, device=rays.device, dtype=torch.int32)
+    _abi.check(_abi.lib().naf_fine_depths(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(sigma), _abi.ptr(u), _abi.ptr(z_all),
+                                          _abi.ptr(weights), n, S, int(n_fine), int(bool(perturb)), int(bool(det)),
+                                          int(seed) & (2 ** 64 - 1), 0, _abi.ptr(scratch), _abi.stream_ptr()), "fine_depths")
+    return z_all, weights
+
+
+@torch.no_grad()
+def render_samples(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_precision=None, want_sigma=True, want_depth=True):
+    """Forward render with the per-sample quantities of the coarse -> fine pass (render.py:113-126, 203-211):
+    -> (acc [n], sigma [n, S] or None, optical_depth [n, S] or None).  optical_depth[r, s] is the running line integral
+    sum_{s' <= s} sigma * dist (a wave prefix sum in the MLP kernel); its last column equals acc."""
+    rays = rays.contiguous().float()
+    n = rays.shape[0]
+    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed)
+    ws = workspace(cfg, n * cfg.n_samples, rays.device)
+    acc = torch.empty(n, device=rays.device, dtype=torch.float32)
+    sigma = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_sigma else None
+    depth = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_depth else None
+    enc = net.encoder
+    _abi.check(_abi.lib().naf_render_forward_samples(
+        _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(enc.embeddings.detach().contiguous()), _abi.ptr(_offsets(enc, rays.device)),
+        _abi.ptr(net.packed_mlp().contiguous()), _abi.ptr(acc), _abi.ptr(sigma), _abi.ptr(depth), n, ctypes.byref(cfg), _abi.ptr(ws),
+        _abi.stream_ptr()), "render_forward_samples")
+    _bump(rays.device)
+    return acc, sigma, depth
 
 
 @torch.no_grad()

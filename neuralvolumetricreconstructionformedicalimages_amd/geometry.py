@@ -101,6 +101,33 @@ class RayGenerator:
             float(self.near), float(self.far), int(g.mode == "parallel"), _abi.stream_ptr()), "generate_rays")
         return out
 
+    def draw(self, valid_lists, rays_per_list, seed, projections=None, first=0, count=None, rays_out=None, want_pixels=True):
+        """`rays_per_list` distinct entries of each list in `valid_lists` (int64 device tensors of flat pixel indices),
+        drawn on the device by `naf_draw_scan_rays` -> (pixels [n] or None, target [n] or None, rays [n, 8]).
+        `first` / `count` select a slice of the len(valid_lists) * rays_per_list draws (data-parallel shards)."""
+        g = self.geo
+        k = len(valid_lists)
+        total = k * int(rays_per_list)
+        count = total - first if count is None else int(count)
+        st = _abi.ScanDraw()
+        st.n_segments, st.rays_per_segment = k, int(rays_per_list)
+        for j, v in enumerate(valid_lists):
+            if v.dtype != torch.int64 or not v.is_cuda or not v.is_contiguous():
+                raise RuntimeError("draw: valid-pixel lists must be contiguous int64 device tensors")
+            if v.numel() < rays_per_list:
+                raise ValueError("Cannot take a larger sample than population when 'replace=False'")      # tigre.py:357
+            st.valid[j], st.n_valid[j] = v.data_ptr(), v.numel()
+        rays = rays_out if rays_out is not None else torch.empty(count, 8, device=self.device, dtype=torch.float32)
+        pixels = torch.empty(count, device=self.device, dtype=torch.int64) if want_pixels else None
+        target = torch.empty(count, device=self.device, dtype=torch.float32) if projections is not None else None
+        import ctypes
+        _abi.check(_abi.lib().naf_draw_scan_rays(
+            ctypes.byref(st), _abi.ptr(self.poses), _abi.ptr(projections), _abi.ptr(pixels), _abi.ptr(target), _abi.ptr(rays),
+            int(first), count, self.n_projections, self.W, self.H, float(g.dDetector[0]), float(g.dDetector[1]),
+            float(g.offDetector[0]), float(g.offDetector[1]), float(g.DSD), float(self.near), float(self.far),
+            int(g.mode == "parallel"), int(seed) & (2 ** 64 - 1), _abi.stream_ptr()), "draw_scan_rays")
+        return pixels, target, rays
+
     def rays_for_pixels(self, pixels, out=None):
         """pixels: int64 [n] flat indices proj*H*W + row*W + col  ->  rays [n,8]."""
         pixels = pixels.contiguous().to(torch.int64)

@@ -19,7 +19,7 @@ import torch
 from torch.autograd import Function
 
 from . import _abi
-from .fused import fused_render
+from .fused import fine_depths, fused_render, render_samples
 
 RETURN_PTS = True        # the reference always returns the sample points; switch off to save n*S*12 bytes
 CHECK_NUMERICS = True    # render.py:141-144 prints on NaN/Inf (costs one host sync per chunk)
@@ -125,11 +125,33 @@ def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_
     if not perturb:
         t_rand = None
     fine = net_fine is not None and n_fine > 0
-    fused = (not fine) and raw_noise_std == 0.0 and getattr(net, "fused_supported", lambda: False)()
+    can_fuse = raw_noise_std == 0.0 and getattr(net, "fused_supported", lambda: False)()
+    fused = (not fine) and can_fuse
+    # coarse -> fine with both networks in the fused shape: three launches per pass instead of the reference's ATen soup --
+    # coarse forward with per-sample sigma, naf_fine_depths (weights, cdf prefix sum, inverse sampling, sort), fine render
+    # at the explicit depths.  The fine depths carry no gradient (render.py:121) and train.py's loss only reads "acc", so
+    # the coarse pass runs without a graph: "acc0" / "weights0" come back detached here.
+    fused_fine = (fine and can_fuse and getattr(net_fine, "fused_supported", lambda: False)() and n_samples >= 3
+                  and n_samples <= 1024 and n_samples + n_fine <= 2048)
 
     z_vals = pts = None
-    if RETURN_PTS or not fused:
+    if RETURN_PTS or not (fused or fused_fine):
         z_vals, pts = _sample(rays, n_samples, perturb, net.bound, t_rand)
+    if fused_fine:
+        acc0, sigma, _ = render_samples(rays, net, n_samples, perturb, t_rand=t_rand, want_depth=False)
+        det = perturb == 0.0
+        u = None if det else torch.rand(n_rays, n_fine, device=rays.device)        # same RNG stream position as render.py:230
+        z_all, weights0 = fine_depths(rays, sigma, n_fine, perturb, t_rand=t_rand, u=u, det=det)
+        acc = fused_render(rays, net_fine, n_samples + n_fine, False, z_vals=z_all)
+        ret = {"acc0": acc0, "weights0": weights0, "pts0": pts, "acc": acc}
+        if RETURN_PTS:
+            ret["pts"] = _points(rays, z_all, net.bound)
+            ret["tv_loss"] = torch.sum(torch.abs(ret["pts"][:, 1:, :] - ret["pts"][:, :-1, :])) * 0.1
+        if CHECK_NUMERICS:
+            for k in ret:
+                if ret[k] is not None and not torch.isfinite(ret[k]).all():
+                    print(f"! [Numerical Error] {k} contains nan or inf.")
+        return ret
     if fused:
         acc = fused_render(rays, net, n_samples, perturb, t_rand=t_rand)
         weights = None

@@ -101,6 +101,8 @@ class Trainer:
         backend = cfg.get("backend", {}) or {}
         self.loss_mode = backend.get("loss", "chunk_sum")
         self.i_log = int(cfg["log"].get("i_log", 100))      # steps between train/loss scalars (reading the loss synchronises)
+        self._plain_weights = {}
+        self._even_shards = cfg["train"]["n_rays"] % max(self.world, 1) == 0     # every rank then holds n_rays / world rays
 
         self.expdir = osp.join(cfg["exp"]["expdir"], cfg["exp"]["expname"])
         self.ckptdir = osp.join(self.expdir, "ckpt.tar")
@@ -184,7 +186,7 @@ class Trainer:
                 msg = "".join(f", {k}: {float(v):.3g}" for k, v in loss_test.items())
                 print(f"[EVAL] epoch: {idx_epoch}/{self.epochs}{msg}")
 
-            for data in self.train_dloader:
+            for data in self._batches():
                 self.global_step += 1
                 self.net.train()
                 loss_train = self.train_step(data, global_step=self.global_step, idx_epoch=idx_epoch)
@@ -200,6 +202,15 @@ class Trainer:
             self.writer.add_scalar("train/lr", self.optimizer.param_groups[0]["lr"], self.global_step)
             self.lr_scheduler.step()
         print(f"Training complete! See logs in {self.expdir}")
+
+    def _batches(self):
+        """One epoch of training batches.  The reference iterates a DataLoader with batch_size = n_batch = 1 over a dataset
+        whose items already are whole ray batches (trainer.py:32-37); with the fused engine the items are consumed directly --
+        the collate step would only copy every tensor once more to add a batch dimension of one."""
+        if self.engine is not None and self.conf["train"]["n_batch"] == 1:
+            dset = self.train_dset
+            return (dset[i] for i in range(len(dset)))
+        return iter(self.train_dloader)
 
     def save_checkpoint(self, idx_epoch):
         if self.rank != 0:                                 # replicas are identical; rank 0 writes
@@ -222,7 +233,17 @@ class Trainer:
             mask_full = get_ptycho_mask(full_proj.reshape(full_proj.shape[-2:]), threshold=0.007)
             coords = data["coords"].reshape(-1, 2).long()
             mask = mask_full[coords[:, 0], coords[:, 1]]
-        else:
+        else:                                              # no mask: the weights depend on the batch size only
+            key = (n, self.loss_mode, self.world)
+            if key not in self._plain_weights:
+                ones = torch.ones(n, dtype=torch.bool, device=self.device)
+                if self.group is not None:
+                    w = ones.float() / float(n * self.world) if self._even_shards else None
+                else:
+                    w = chunk_mean_weights(ones, 200, self.loss_mode)
+                self._plain_weights[key] = w
+            if self._plain_weights[key] is not None:
+                return self._plain_weights[key]
             mask = torch.ones(n, dtype=torch.bool, device=self.device)
         if self.group is not None:                         # global masked mean over all ranks' rays
             from .dist import global_mean_weights
@@ -231,9 +252,11 @@ class Trainer:
 
     def train_step(self, data, global_step, idx_epoch):
         if self.engine is not None:
-            rays = data["rays"].reshape(-1, 8).contiguous()
-            projs = data["projs"].reshape(-1).float().contiguous()
-            weight = self.ray_weights(data, rays.shape[0]).contiguous()
+            rays = data["rays"].reshape(-1, 8)
+            projs = data["projs"].reshape(-1)
+            if projs.dtype != torch.float32:
+                projs = projs.float()
+            weight = self.ray_weights(data, rays.shape[0])
             n = rays.shape[0]
             loss = self.engine.train_step(rays, projs, weight, ray_base=(global_step * self.world + self.rank) * n)
             if self.i_log > 0 and global_step % self.i_log == 0:

@@ -307,7 +307,7 @@ def test_input_gradient_modes_match_the_oracle():
     y = enc(p, 0.3)
     w = torch.randn_like(y)
     (y * w).sum().backward()
-    eps = 1e-3
+    eps = 2e-4                                                        # finest cell of this grid: 0.6 / 64 = 9.4e-3
     for d in range(3):
         step = torch.zeros(3, device="cuda")
         step[d] = eps

@@ -115,3 +115,48 @@ def test_adam_matches_torch(lp):
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
     if lp is not None:
         assert torch.equal(shadow.cpu(), p.cpu().to(lp))
+
+
+def test_draw_scan_rays_distinct_valid_uniform_and_shardable():
+    """naf_draw_scan_rays (tigre.py:354-372 on the device): distinct pixels, all from the valid lists, their measured
+    values and rays; a new seed gives a new draw; slices of one draw (data-parallel shards) tile it; roughly uniform."""
+    from neuralvolumetricreconstructionformedicalimages_amd import phantom
+    from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
+    geo = ConeGeometry(phantom.scan_geometry(16, "cone"))                    # 32 x 32 detector
+    gen = RayGenerator(geo, np.linspace(0, np.pi, 5)[:-1], torch.device("cuda"))
+    hw = gen.pixels_per_projection
+    g = torch.Generator().manual_seed(0)
+    projs = torch.rand(4 * hw, generator=g)
+    projs[torch.rand(4 * hw, generator=g) < 0.4] = 0.0                       # 40 % of the pixels saw nothing
+    projs = projs.cuda()
+    valid = [(torch.nonzero(projs[i * hw:(i + 1) * hw] > 0).reshape(-1) + i * hw).contiguous() for i in range(4)]
+    per = 300
+    pix, tgt, rays = gen.draw(valid[1:3], per, seed=7, projections=projs)
+    assert pix.shape == (600,) and tgt.shape == (600,) and rays.shape == (600, 8)
+    for j, lst in enumerate(valid[1:3]):
+        seg = pix[j * per:(j + 1) * per]
+        assert len(torch.unique(seg)) == per                                 # replace=False
+        assert bool(torch.isin(seg, lst).all())                              # only pixels that measured something
+    assert torch.equal(tgt, projs[pix]) and bool((tgt > 0).all())
+    assert torch.equal(rays, gen.rays_for_pixels(pix))                       # same bits as the pixel-list ray generator
+    pix2, _, _ = gen.draw(valid[1:3], per, seed=8, projections=projs)
+    assert not torch.equal(pix, pix2)
+    # shards: two ranks with the same seed take [0, 250) and [250, 600) of the same draw
+    a, ta, ra = gen.draw(valid[1:3], per, seed=7, projections=projs, first=0, count=250)
+    b, tb, rb = gen.draw(valid[1:3], per, seed=7, projections=projs, first=250, count=350)
+    assert torch.equal(torch.cat([a, b]), pix) and torch.equal(torch.cat([ta, tb]), tgt) and torch.equal(torch.cat([ra, rb]), rays)
+    # drawing the whole list is a permutation of it
+    n1 = valid[0].numel()
+    full, _, _ = gen.draw(valid[:1], n1, seed=3)
+    assert torch.equal(torch.sort(full).values, valid[0])
+    # uniformity: over many seeds every valid pixel of a list is drawn about equally often
+    counts = torch.zeros(4 * hw, device="cuda")
+    trials, m = 400, 64
+    for s_ in range(trials):
+        p_, _, _ = gen.draw(valid[3:4], m, seed=1000 + s_)
+        counts[p_] += 1
+    c = counts[valid[3]]
+    expect = trials * m / valid[3].numel()
+    assert float(counts.sum()) == trials * m and float((c - expect).abs().max()) < 6 * expect ** 0.5 + 3
+    with pytest.raises(ValueError, match="larger sample than population"):
+        gen.draw(valid[:1], n1 + 1, seed=1)
