@@ -363,7 +363,7 @@ def main():
                                    f"{n} rays/step/GPU (reference n_rays=1024) = {min(n, RAYS_PER_PROJECTION)} distinct valid pixels from "
                                    f"each of {max(1, n // RAYS_PER_PROJECTION)} projections, drawn on the device inside the step; perturb=True",
                        "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "parallelism": f"dp{world}"},
-            "final_loss": final_loss, "scatter_overflow_last_step": overflow,
+            "final_loss": final_loss, "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n),
             "scatter_overflow_fraction": overflow / (points_per_launch * 128.0),
             "library_kernels_ms_per_step": round(kernel_ms, 4),
             "sampling_and_gaps_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 4),

@@ -190,6 +190,9 @@ typedef struct naf_render_cfg {
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */
 int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host);
 
+/* The same per level: counts_host[32] (host memory), entry l = records of level l that fell back to atomics. */
+int naf_scatter_overflow_levels(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *counts_host);
+
 /* Workspace size in bytes for naf_render_* / naf_field_forward over `n_points` points (= n_rays * n_samples for the
  * render entry points): feature and feature-gradient tensors [L, n_points, C] plus the MLP-gradient slabs. */
 size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "naf_integrate_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "naf_integrate_backward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "naf_scatter_overflow_count": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "naf_scatter_overflow_levels": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32 * 32)]),
     "naf_render_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
     "naf_render_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_forward_samples": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),

@@ -740,23 +740,26 @@ static uint32_t backward_lds_bytes() {
 struct Workspace {
     unsigned char *feat, *dfeat;
     float *slabs, *grad_acc;
-    unsigned char *regions;      // binned scatter: record regions [level][bucket][tile][slot_cap]
-    uint32_t *counts;            //                 records per region
+    unsigned char *regions;      // binned scatter: record blocks [level slot][tile][slots], bucket-sorted per tile
+    uint32_t *counts;            //                 run words [level slot][bucket][tile] = start | length << 16
     uint32_t *overflow;          //                 contributions that fell back to atomics (diagnostic counter)
     uint32_t *gmax;              //                 bit pattern of max |feature gradient| of the step (fixed-point scale)
-    float *sums;                 //                 finished row sums [level][bucket][local][C] between pass 2 and pass 3
     BinPlan plan;
     bool binned;
     size_t bytes;
 };
 
 constexpr uint64_t kBinMinPoints = 1u << 13;             // measured: 128 rays x 192 samples 0.62 ms (atomics) vs 0.36 ms (binned) per step
-constexpr size_t kBinBudgetBytes = (size_t)24 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
+constexpr size_t kBinBudgetBytes = (size_t)40 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
                                                          // step fit, so the reducer gets 1024 workgroups to balance over 256 CUs
 
+// bytes of a pair record (scatter_binned.h): head + two corners x C values (fp32 in parity mode, bf16 packed in pairs otherwise)
 static size_t record_bytes(const naf_render_cfg *cfg) {
-    return cfg->mlp_precision == NAF_F32 ? 4u * (1u + cfg->C) : 4u * (1u + (cfg->C + 1u) / 2u);
+    return cfg->mlp_precision == NAF_F32 ? 4u * (1u + 2u * cfg->C) : 4u * (1u + 2u * ((cfg->C + 1u) / 2u));
 }
+// pass-1 tile shape, the host mirror of BinShape<Rec>
+static uint32_t bin_threads(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 12 ? 512u : 256u; }
+static uint32_t bin_points_per_thread(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 20 ? 2u : 1u; }
 
 static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan *plan) {
     if (cfg->scatter_mode == NAF_SCATTER_ATOMIC || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
@@ -764,21 +767,17 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
-    // pass-1 tile: one point per thread, 512 threads for 8-byte records; its records wait in LDS slots [bucket][slot_cap]
-    // 1024-point tiles when a level needs >= 256 buckets (T = 2^21 and up): runs would otherwise shrink below a 128-byte line
-    const uint32_t tile = record_bytes(cfg) <= 8 ? (log2_nb >= 7 ? 1024u : 512u) : 256u;
+    const size_t rec = record_bytes(cfg);
+    const uint32_t tile = bin_threads(cfg) * bin_points_per_thread(cfg);
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
-    const uint32_t slot_mean = std::max<uint32_t>(1u, (tile * 8u) >> log2_nb);
-    // mean + 4 sigma of the (near-Poisson) run length: the tail beyond it is ~3e-5 per run, and an overflowing record is
-    // still correct (global atomic), just slower.  <= 128 because the reducer reads a region with two loads per lane.
-    // 8-byte records: a multiple of 16 slots, so regions start on 128-byte lines and pass 1 writes whole lines only --
-    // HBM takes ragged 16-byte-granular runs at ~3 TB/s but line-aligned ones at > 5 TB/s (tools/write_pattern_bench.hip).
-    const uint32_t want = slot_mean + (uint32_t)std::ceil(4.0 * std::sqrt((double)slot_mean));
-    plan->slot_cap = std::min(128u, record_bytes(cfg) == 8 ? (want + 15u) & ~15u : (want + 1u) & ~1u);
-    plan->max_local_rows = (uint32_t)((maxT + (1ull << log2_nb) - 1) >> log2_nb);
-    const size_t per_level = (((size_t)plan->n_tiles << log2_nb) * plan->slot_cap) * record_bytes(cfg);
+    // A tile's block holds four pair records per point plus the second halves of unpaired pairs (1.6 % on average): a quarter
+    // on top never fills up in practice, and a tile that does fill it spills to atomics (still correct).  A multiple of 32
+    // records: blocks start on 128-byte lines whatever the record size.
+    plan->slots = std::min<uint32_t>(65504u, ((tile * 5u) + 31u) & ~31u);
+    plan->max_local_rows = (uint32_t)((((maxT + (1ull << log2_nb) - 1) >> log2_nb) + 63u) & ~63ull);
+    const size_t per_level = (size_t)plan->n_tiles * plan->slots * rec;
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
     if (per_level_launches(cfg)) plan->levels_per_pass = 1;
     return true;
@@ -799,17 +798,14 @@ static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points)
     w.counts = nullptr;
     w.overflow = nullptr;
     w.gmax = nullptr;
-    w.sums = nullptr;
     if (w.binned) {
-        const size_t n_streams = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * w.plan.n_tiles;     // regions
-        const size_t stream_bytes = (n_streams * w.plan.slot_cap * record_bytes(cfg) + 255) & ~(size_t)255;
+        const size_t n_runs = ((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * w.plan.n_tiles;
+        const size_t block_bytes = ((size_t)w.plan.levels_per_pass * w.plan.n_tiles * w.plan.slots * record_bytes(cfg) + 255) & ~(size_t)255;
         w.regions = (unsigned char *)base + w.bytes;
-        w.counts = (uint32_t *)(w.regions + stream_bytes);
-        w.overflow = w.counts + n_streams;
-        w.gmax = w.overflow + 1;
-        w.bytes += stream_bytes + (((n_streams + 2) * 4 + 255) & ~(size_t)255);
-        w.sums = (float *)((unsigned char *)base + w.bytes);
-        w.bytes += ((((size_t)w.plan.levels_per_pass << w.plan.log2_nb) * sums_rows(w.plan) * cfg->C * 4) + 255) & ~(size_t)255;
+        w.counts = (uint32_t *)(w.regions + block_bytes);
+        w.overflow = w.counts + n_runs;                      // [0] total, [1 + level] per level
+        w.gmax = w.overflow + 33;
+        w.bytes += block_bytes + (((n_runs + 33 + 1) * 4 + 255) & ~(size_t)255);
     }
     return w;
 }
@@ -957,23 +953,25 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     return check_launch("mlp_grad_reduce_kernel");
 }
 
-template <typename P, uint32_t C, typename Rec, uint32_t NT>
-static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                                 const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
-                                 const naf_grad_buckets *buckets, hipStream_t s) {
+template <typename P, uint32_t C, typename Rec>
+static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                              const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
+                              const naf_grad_buckets *buckets, hipStream_t s) {
     using FT = typename P::feat_t;
+    constexpr uint32_t NT = BinShape<Rec>::kThreads, PTS = BinShape<Rec>::kPoints;
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
     // position is evaluated once per point, and stores drain behind the next level: 3.85 -> 3.53 ms at 65 536 rays),
     // four when tiles are scarce (1 024-ray steps: 0.093 -> 0.071 ms)
     constexpr uint32_t kLvMany = 16u, kLvFew = 4u;
     const BinPlan &plan = w.plan;
-    const bool many = plan.n_tiles >= 3072u;
+    if (plan.tile_points != NT * PTS) return fail(NAF_ERR_LAUNCH, "binned scatter: plan / kernel tile mismatch");
+    const bool many = plan.n_tiles >= 1536u;
     const uint32_t LV = many ? kLvMany : kLvFew;
-    auto bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, NT, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, NT, kLvFew>;
+    auto bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, NT, PTS, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, NT, PTS, kLvFew>;
     auto red = scatter_reduce_kernel<C, Rec>;
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;
-    const uint32_t bin_lds = 2u * NB * 4u + NB * plan.slot_cap * (uint32_t)sizeof(Rec);
+    const uint32_t bin_lds = (2u * NB + 4u) * 4u + plan.slots * (uint32_t)sizeof(Rec);
     if (int rc = raise_lds_limit(red, red_lds, "binned scatter: cannot raise dynamic LDS limit (reduce)")) return rc;
     if (int rc = raise_lds_limit(bin, bin_lds, "binned scatter: cannot raise dynamic LDS limit (bin)")) return rc;
     static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
@@ -986,17 +984,14 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
                            offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan);
         return check_launch("scatter_bin_kernel");
     };
-    // passes 2 + 3 over the level slots [ly0, ly0 + nl) of a bin pass that started at level l0
+    // pass 2 over the level slots [ly0, ly0 + nl) of a bin pass that started at level l0
     auto launch_reduce = [&](uint32_t l0, uint32_t ly0, uint32_t nl) -> int {
         ProfScope prof_(per_level ? level_name(red_names, l0 + ly0) : "scatter_reduce_kernel", s);
         // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles.
         // (A reducer workgroup owns a CU's LDS, so 256 run at a time: 512 or more unsplit ones already come in full rounds.)
         const uint32_t n_split = NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl)));
         hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                           grad_table, w.sums, w.gmax, cfg->H, l0, ly0, plan);
-        if (n_split == 1u)      // pass 3: the sums are in [bucket][local] order; add them to the table row-major
-            hipLaunchKernelGGL((scatter_apply_kernel<C>), dim3((plan.max_local_rows + 63u) / 64u, nl, NB / 64u), dim3(256), 0, s,
-                               w.sums, offsets, grad_table, cfg->H, l0, ly0, plan);
+                           grad_table, w.gmax, l0, ly0, plan);
         return check_launch("scatter_reduce_kernel");
     };
     if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {
@@ -1020,18 +1015,6 @@ static int run_binned_scatter_nt(const SrcRays &src, const void *dfeat, const in
     return NAF_OK;
 }
 
-template <typename P, uint32_t C, typename Rec>
-static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                              const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
-                              const naf_grad_buckets *buckets, hipStream_t s) {
-    if constexpr (sizeof(Rec) <= 8) {                            // tile size chosen by make_bin_plan
-        if (w.plan.tile_points == 1024u) return run_binned_scatter_nt<P, C, Rec, 1024u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
-        return run_binned_scatter_nt<P, C, Rec, 512u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
-    } else {
-        return run_binned_scatter_nt<P, C, Rec, 256u>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
-    }
-}
-
 // Table-gradient scatter of the levels [lv_begin, lv_end).
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
@@ -1039,8 +1022,8 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
                                     const naf_grad_buckets *buckets = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, RecF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
-        return run_binned_scatter<P, C, RecBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
+        return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
     }
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("hash_backward_kernel_L");
@@ -1062,7 +1045,7 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s) {
-    if (w.binned && hipMemsetAsync(w.overflow, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
+    if (w.binned && hipMemsetAsync(w.overflow, 0, 33 * 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
     if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s);
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
         return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
@@ -1167,6 +1150,15 @@ extern "C" int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_
     *count_host = 0;
     if (!w.binned) return NAF_OK;
     if (hipMemcpy(count_host, w.overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(NAF_ERR_LAUNCH, "scatter_overflow_count: copy failed");
+    return NAF_OK;
+}
+
+extern "C" int naf_scatter_overflow_levels(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *counts_host) {
+    if (!cfg || !workspace || !counts_host) return fail(NAF_ERR_INVALID_ARGUMENT, "scatter_overflow_levels: null pointer");
+    const Workspace w = carve(const_cast<void *>(workspace), cfg, n_points);
+    std::memset(counts_host, 0, 32 * sizeof(uint32_t));
+    if (!w.binned) return NAF_OK;
+    if (hipMemcpy(counts_host, w.overflow + 1, 32 * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(NAF_ERR_LAUNCH, "scatter_overflow_levels: copy failed");
     return NAF_OK;
 }
 

@@ -7,78 +7,110 @@
 // A level of the table gets ~50-200 contributions per row per step, but they are hash-scattered, so no locality trick
 // removes them -- they have to be ROUTED to an owner instead (a one-digit radix multisplit on the row index):
 //
-//   pass 1  bin      one workgroup = one tile of 512 points x LV consecutive levels (all 16, or 4 when tiles are scarce).  Per level every thread takes
-//                    an LDS slot for each of its 8 contributions in the bucket's staging run (bucket = row & (NB-1), one
-//                    returning LDS atomic per record) and writes the record (row >> log2 NB, w*g[0..C)) there; the runs are
-//                    then copied to fixed-size global REGIONS [level][tile][bucket][slot_cap] with 16-byte stores that
-//                    cover whole 128-byte lines, and the run lengths go to counts[level][bucket][tile].  No global
-//                    atomics, no prefix sums between workgroups; a run that outgrows its region (~3e-5 of them) falls
-//                    back to global atomics for the excess, so any capacity is CORRECT.
-//   pass 2  reduce   one workgroup = one (bucket, level): streams the bucket's regions of all tiles (several loads in
-//                    flight per lane), accumulates rows  row >> log2(NB)  in LDS as 64-bit fixed point (ds_add_u64), then
-//                    adds the finished rows to the gradient table with plain read-modify-writes -- it is the only owner
-//                    of those rows.
+//   pass 1  bin      one workgroup = one tile of NT x PTS points x LV consecutive levels (all 16, or 4 when tiles are scarce).
+//                    Per level an EXACT multisplit of the tile's records by bucket, in LDS: histogram (one LDS atomic per
+//                    record), exclusive scan of the NB counters, placement (one returning LDS atomic per record) -- the
+//                    tile's records end up bucket-sorted and DENSE in a staging block, which is copied to the tile's
+//                    global block [level][tile][slots] with 16-byte stores of whole 128-byte lines; (start, length) of every
+//                    bucket's run goes to runs[level][bucket][tile].  No global atomics, no prefix sums between
+//                    workgroups, and no per-bucket capacity: however skewed a tile is (all samples of a ray in one cell,
+//                    rays parallel to an axis, ...) its runs simply have different lengths.  Only a tile whose TOTAL
+//                    exceeds the block (more than a quarter of its x-neighbour pairs unpaired; never seen) spills the
+//                    excess to global atomics, so the result is correct for any input.
+//   pass 2  reduce   one workgroup = one (bucket, level): streams the bucket's run of every tile (several loads in
+//                    flight per lane), accumulates its rows in LDS as 64-bit fixed point (ds_add_u64), then adds the finished
+//                    rows to the gradient table with plain, coalesced read-modify-writes -- it is the only owner of those rows.
 //
-// What the memory system wants (tools/write_pattern_bench.hip, MI355X): the 64 runs of a tile written next to each other
-// ([tile][bucket] order) and line-aligned at both ends reach > 5 TB/s; the same bytes as ragged 16-byte-granular runs, or
-// [bucket][tile] order at a 768-byte stride, only ~3 TB/s.  Waves never wait for these stores: the barriers inside the
-// level loop order LDS traffic only (lds_barrier), and the one global load of the loop is consumed before the stores.
+// PAIR RECORDS.  The two x-neighbour corners of a cell sit in rows r and r' with r ^ r' = 2^e - 1: on hashed levels
+// r = x ^ h(y,z) and r' = (x+1) ^ h(y,z) (hashencoder.cu:36-52: the prime of dimension 0 is 1), on dense levels r' = r + 1,
+// and x ^ (x+1) is the mask of the trailing ones of x plus one bit.  With probability 1 - 2^-6 the mask is below 64, i.e. both
+// rows lie in the same aligned block of 64 rows.  So the bucket is taken from the bits ABOVE the low six, both corners
+// reach the same owner, and ONE record carries both:
+//     { local row of the first corner | xor mask << 16,  C values of the first corner,  C values of the second }
+// 12 bytes instead of 2 x 8 for two bf16 channels -- a quarter fewer bytes through HBM in both passes, half the LDS
+// atomics and staging writes in pass 1, half the record loads and index arithmetic in pass 2.  The rare pair whose mask is
+// >= 64 travels as two records with mask 0 and a zero second half.
 //
-// Bucket = LOW bits of the row (rotated, see bucket_of), so dense coarse levels (whose rows are spatially ordered and
-// heavily skewed toward the volume centre) spread as evenly as the hashed ones.
+// Bucket = bits [6, 6 + log2 NB) of the row, local row = remaining high bits : low six bits.  A bucket's local rows
+// 64 k .. 64 k + 63 are 64 CONSECUTIVE table rows, so the reducer adds its sums to the table in place, coalesced.
+// Consecutive cells of a ray that runs along x share their 64-row block and therefore their bucket: runs of such tiles come
+// in clusters (measured with a fixed per-bucket capacity of mean + 4 sigma: 1-2 % of the records of levels 4..6 overflowed,
+// 10 % on some projections) -- which is why the multisplit is exact instead of slotted.
+//
+// On the coarsest levels (cells wider than the sample spacing) consecutive samples of a ray fall into the same cell: each
+// run of equal cells is merged inside the wave first (segmented scan over DPP row shifts) and only its last lane emits.
+//
+// What the memory system wants (tools/write_pattern_bench.hip, MI355X): line-aligned, dense stores reach > 5 TB/s, ragged
+// 16-byte-granular ones ~3 TB/s.  Waves never wait for these stores: the barriers inside the level loop order LDS traffic
+// only (lds_barrier), and the global loads of the loop are consumed before the stores.
 #pragma once
 
 #include "naf_device.h"
 
 namespace naf {
 
+// ---- records ---------------------------------------------------------------------------------------------------
+// w[0] = local row of the first corner (< 2^16) | xor mask to the second corner's local row << 16 (0: no second corner)
 template <uint32_t C>
-struct RecF32 {                       // row + C fp32 values
-    uint32_t w[1 + C];
-    __device__ __forceinline__ void set(uint32_t row, const float (&v)[C]) {
-        w[0] = row;
+struct PairF32 {                      // 2 x C fp32 values
+    static constexpr uint32_t kHalf = C;
+    uint32_t w[1 + 2 * C];
+    __device__ __forceinline__ void set(uint32_t head, const float (&a)[C], const float (&b)[C]) {
+        w[0] = head;
 #pragma unroll
-        for (uint32_t c = 0; c < C; ++c) w[1 + c] = __float_as_uint(v[c]);
+        for (uint32_t c = 0; c < C; ++c) { w[1 + c] = __float_as_uint(a[c]); w[1 + C + c] = __float_as_uint(b[c]); }
     }
-    __device__ __forceinline__ float value(uint32_t c) const { return __uint_as_float(w[1 + c]); }
+    __device__ __forceinline__ float value(uint32_t half, uint32_t c) const { return __uint_as_float(w[1 + half * C + c]); }
 };
 
 template <uint32_t C>
-struct RecBF16 {                      // row + C bf16 values (packed two per dword)
-    uint32_t w[1 + (C + 1) / 2];
-    __device__ __forceinline__ void set(uint32_t row, const float (&v)[C]) {
-        w[0] = row;
+struct PairBF16 {                     // 2 x C bf16 values (packed two per dword)
+    static constexpr uint32_t kHalf = (C + 1) / 2;
+    uint32_t w[1 + 2 * kHalf];
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // plain casts: one v_cvt_pk_bf16_f32 per pair
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 pk;
+        pk[0] = (__bf16)lo;
+        pk[1] = (__bf16)hi;
+        return __builtin_bit_cast(uint32_t, pk);
+    }
+    __device__ __forceinline__ void set(uint32_t head, const float (&a)[C], const float (&b)[C]) {
+        w[0] = head;
 #pragma unroll
-        for (uint32_t c = 0; c < C; c += 2) {              // plain casts: hipcc emits one v_cvt_pk_bf16_f32 per pair
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            bf16x2 pk;
-            pk[0] = (__bf16)v[c];
-            pk[1] = c + 1 < C ? (__bf16)v[c + 1] : (__bf16)0.0f;
-            w[1 + c / 2] = __builtin_bit_cast(uint32_t, pk);
+        for (uint32_t c = 0; c < C; c += 2) {
+            w[1 + c / 2] = pack2(a[c], c + 1 < C ? a[c + 1] : 0.0f);
+            w[1 + kHalf + c / 2] = pack2(b[c], c + 1 < C ? b[c + 1] : 0.0f);
         }
     }
-    __device__ __forceinline__ float value(uint32_t c) const {
-        const uint32_t p = w[1 + c / 2];
+    __device__ __forceinline__ float value(uint32_t half, uint32_t c) const {
+        const uint32_t p = w[1 + half * kHalf + c / 2];
         return __uint_as_float((c & 1u) ? (p & 0xffff0000u) : (p << 16));
     }
 };
 
 struct BinPlan {
-    uint32_t tile_points;     // points per pass-1 workgroup (= its thread count)
+    uint32_t tile_points;     // points per pass-1 workgroup (threads x points per thread)
     uint32_t n_tiles;
     uint32_t log2_nb;         // NB = buckets per level
-    uint32_t slot_cap;        // records per (level, bucket, tile) region = LDS slots per bucket in pass 1
+    uint32_t slots;           // records per (level, tile) block = LDS staging slots of pass 1 (a multiple of 32, < 2^16)
     uint32_t levels_per_pass;
-    uint32_t max_local_rows;  // ceil(max T_l / NB)
+    uint32_t max_local_rows;  // ceil(max T_l / NB), rounded up to a multiple of 64
+};
+
+// Pass-1 shape by record size (compile time): 12-byte records (two bf16 channels) get 512 threads x 2 points -- 1024-point
+// tiles, a mean of 64 pair records per bucket, so a reducer wave is full; larger records get smaller tiles (LDS staging).
+template <typename Rec> struct BinShape {
+    static constexpr uint32_t kThreads = sizeof(Rec) <= 12 ? 512u : 256u;
+    static constexpr uint32_t kPoints = sizeof(Rec) <= 20 ? 2u : 1u;
 };
 
 // Fixed-point scale of the reducer.  `gmax_bits` = bit pattern of max |feature gradient| of the step (written by the MLP
 // backward kernel, BEFORE the gradients are rounded to their storage type: rounding can lift a value by at most one ulp of
 // bf16, 2^-8 relative, which the bound below absorbs by using the NEXT power of two).  A contribution is w * g with
-// 0 <= w <= 1, so |v| <= gmax < 2^(E+1) with E = exponent(gmax); pass 1 may merge the up to 64 same-cell contributions of a
-// wave into one record, so a record is bounded by 64 * 2^(E+1).
-// fixed = v * 2^(kFixHead - E - 1) keeps a single contribution below 2^kFixHead and a record below 2^(kFixHead + 6): with
-// kFixHead = 31 that leaves 63 - 37 = 26 bits for the sum (6.7e7 maximal records per row) and 31 significant bits below
+// 0 <= w <= 1, so |v| <= gmax < 2^(E+1) with E = exponent(gmax); pass 1 may merge the up to 16 same-cell contributions of a
+// DPP row into one record, so a record is bounded by 16 * 2^(E+1).
+// fixed = v * 2^(kFixHead - E - 1) keeps a single contribution below 2^kFixHead and a record below 2^(kFixHead + 4): with
+// kFixHead = 31 that leaves 63 - 35 = 28 bits for the sum (2.7e8 maximal records per row) and 31 significant bits below
 // the largest gradient -- seven more than the fp32 mantissa the atomic path accumulates with.
 // A non-finite gradient anywhere in the step makes the exponent field 255: the reducer then writes NaN into every row sum
 // (the atomic path would have poisoned the touched rows; the divergence stays visible instead of turning into garbage).
@@ -89,208 +121,249 @@ __device__ __forceinline__ int fixed_shift(uint32_t gmax_bits) {
     return (e == 0 || e == 255) ? 0 : kFixHead - (e - 127) - 1;
 }
 // fp32 -> 64-bit fixed point round(v * 2^shift), branch-free: the product is exact in double, and adding 1.5 * 2^52
-// leaves the (two's complement) integer in the low mantissa bits for |v * 2^shift| < 2^51 (here < 2^38 per record).
+// leaves the (two's complement) integer in the low mantissa bits for |v * 2^shift| < 2^51 (here < 2^36 per record).
 __device__ __forceinline__ long long to_fixed(float v, double scale) {
     const double d = (double)v * scale + 6755399441055744.0;
     return __double_as_longlong(d) - 0x4338000000000000ll;
 }
 
-// Row <-> (bucket, local row).  local = row >> log2 NB; the bucket is the low log2 NB bits of the row ROTATED by a function
-// of the local row, (row + local + (local >> 10)) & (NB-1): for a fixed local row the NB candidates still map one-to-one to
-// the buckets, so (bucket, local) identifies the row, but neighbouring corners no longer collide.  On dense and
-// uint32-wrapped dense levels row = x + s1 y + s2 z with s1 = s2 = 1 (mod 64): with the plain low bits the eight corners
-// of a cell fall into buckets b + {0,1,1,2,1,2,2,3}, and the triple hits overflow the staging runs (0.5 ms per step of
-// fallback atomics); rotated they fall into b + {0,1,2,3,3,4,5,6}.
-// Hashed levels scatter their rows anyway and skip the rotation (three VALU operations per record in pass 1): `twist` is 1
-// on dense / wrapped-dense levels, 0 on hashed ones -- the same rule in all three passes (level_twist).
-__device__ __forceinline__ uint32_t bucket_twist(uint32_t local) { return local + (local >> 10); }
-__device__ __forceinline__ uint32_t level_twist(const LevelMeta &m) { return m.mode < kHashMask ? 1u : 0u; }
-__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb, uint32_t twist) {
-    return (row + (twist ? bucket_twist(row >> log2_nb) : 0u)) & ((1u << log2_nb) - 1u);
+// ---- row <-> (bucket, local row) -------------------------------------------------------------------------------------
+// bucket = bits [6, 6 + log2 NB), local = (row >> (6 + log2 NB)) << 6 | (row & 63)
+__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb) { return (row >> 6) & ((1u << log2_nb) - 1u); }
+__device__ __forceinline__ uint32_t local_of(uint32_t row, uint32_t log2_nb) { return ((row >> (6u + log2_nb)) << 6) | (row & 63u); }
+__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb) {
+    return ((local >> 6) << (6u + log2_nb)) | (bucket << 6) | (local & 63u);
 }
-__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb, uint32_t twist) {
-    return (local << log2_nb) | ((bucket - (twist ? bucket_twist(local) : 0u)) & ((1u << log2_nb) - 1u));
+// local rows a bucket of a level with T rows can hold: whole 64-row blocks
+__device__ __forceinline__ uint32_t local_rows(uint32_t T, uint32_t log2_nb) {
+    return ((T + (64u << log2_nb) - 1u) >> (6u + log2_nb)) << 6;
 }
 
-// rows per bucket in the sums buffer of pass 2 (a multiple of 64: pass 3 works on 64-row blocks)
-__host__ __device__ __forceinline__ size_t sums_rows(const BinPlan &plan) { return ((size_t)plan.max_local_rows + 63u) & ~(size_t)63u; }
-
-// run lengths: [level][bucket][tile] (one coalesced load per 64 tiles in pass 2); records: [level][tile][bucket][slot_cap]
-__device__ __forceinline__ size_t count_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
+// runs: [level slot][bucket][tile] = start | length << 16 (one coalesced load per 64 tiles in pass 2);
+// records: [level slot][tile][slots], the tile's records sorted by bucket
+__device__ __forceinline__ size_t run_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
     return (((size_t)ly << plan.log2_nb) + bucket) * plan.n_tiles + tile;
 }
-__device__ __forceinline__ size_t region_index(const BinPlan &plan, uint32_t ly, uint32_t bucket, uint32_t tile) {
-    return ((((size_t)ly * plan.n_tiles) + tile) << plan.log2_nb) + bucket;
+__device__ __forceinline__ size_t block_index(const BinPlan &plan, uint32_t ly, uint32_t tile) {
+    return ((size_t)ly * plan.n_tiles + tile) * plan.slots;
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: cnt[2][NB] | staging[NB][slot_cap] records.  One workgroup = one tile of NT points (one per thread) x LV
-// consecutive levels: the sample position is evaluated once, and the stores of one level drain while the next level
-// is being computed.  With 8-byte records the launch uses NT = 512: LDS allows two or three workgroups per CU either
-// way, and 16+ resident waves hide the input loads and the staging round trips far better than 8 (5.6 -> 4.7 ms/step).
-template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t LV>
-__global__ void __launch_bounds__(NT, NT == 512u ? 6 : NT == 1024u ? 4 : 1)   // 512 threads: three workgroups (24 waves) per CU -> <= 80 VGPRs
+// LDS: hist[NB] | cursor[NB] | total | staging[slots] records.  One workgroup = one tile of NT x PTS points x LV consecutive
+// levels: the sample positions are evaluated once, and the stores of one level drain while the next level is being computed.
+// Per level: (A) every thread builds the records of its points in registers and counts them per bucket (ds_add_u32),
+// (B) wave 0 turns the histogram into exclusive offsets and publishes (start, length) of every run, (C) every thread takes
+// its slots (ds_add_rtn_u32 on the cursors) and writes its records, (D) the dense, bucket-sorted block leaves for HBM.
+template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t PTS, uint32_t LV>
+__global__ void __launch_bounds__(NT, NT == 512u ? 4 : 2)       // 512 threads: two workgroups (16 waves) per CU -> <= 128 VGPRs
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
-                   float *__restrict__ grad_table, Rec *__restrict__ regions, uint32_t *__restrict__ counts,
+                   float *__restrict__ grad_table, Rec *__restrict__ blocks, uint32_t *__restrict__ runs,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
                    BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t NW = NT / 64u;
-    const uint32_t NB = 1u << plan.log2_nb, CAP = plan.slot_cap;
-    uint32_t *cnt2 = reinterpret_cast<uint32_t *>(smem);
-    Rec *staging = reinterpret_cast<Rec *>(cnt2 + 2u * NB);
-    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: copy-out bucket arithmetic on the SALU
-    for (uint32_t i = threadIdx.x; i < 2u * NB; i += NT) cnt2[i] = 0u;
+    constexpr uint32_t K = sizeof(Rec) / 4u;                    // dwords per record
+    static_assert(PTS == 1u || PTS == 2u, "one or two points per thread");
+    const uint32_t NB = 1u << plan.log2_nb, SLOTS = plan.slots;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cursor = hist + NB;
+    uint32_t *total_p = cursor + NB;                             // 4 dwords (keeps the staging block 16-byte aligned)
+    uint32_t *staging = total_p + 4;                             // [SLOTS][K]
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) hist[i] = 0u;
 
-    // the thread's point.  Threads past the end of the batch take the last point with a zero gradient: their records
+    // the thread's points.  Threads past the end of the batch take the last point with a zero gradient: their records
     // add nothing, and no validity test is needed further down.
-    const uint32_t b_raw = tile * NT + threadIdx.x;
-    const bool valid = b_raw < B;
-    const uint32_t b = valid ? b_raw : B - 1u;
-    float x[3];
-    src.get(b, x);
+    float x[PTS][3];
+    uint32_t bp[PTS];
+    bool valid[PTS];
+#pragma unroll
+    for (uint32_t q = 0; q < PTS; ++q) {
+        const uint32_t b_raw = (tile * PTS + q) * NT + threadIdx.x;
+        valid[q] = b_raw < B;
+        bp[q] = valid[q] ? b_raw : B - 1u;
+        src.get(bp[q], x[q]);
+    }
     const float spacing = src.sample_spacing();
-    // this level's feature gradient, requested one level ahead (see the note at the copy-out)
-    RawVec<FT, C> graw;
-    float g[C];
-    if (blockIdx.y * LV < n_levels) raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + b) * C, graw);
-    raw_unpack<FT, C>(graw, g);
+    // this level's feature gradients, requested one level ahead (see the note at the barrier)
+    RawVec<FT, C> graw[PTS];
+    float g[PTS][C];
+    if (blockIdx.y * LV < n_levels) {
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + bp[q]) * C, graw[q]);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < PTS; ++q) raw_unpack<FT, C>(graw[q], g[q]);
     __syncthreads();
-    uint32_t n_overflow = 0;
+    uint32_t n_overflow = 0, n_overflow_level = 0;               // records that did not fit (whole kernel / current level)
 
+    constexpr uint32_t kNoRow = 0xffffffffu;
     for (uint32_t it = 0; it < LV; ++it) {
         const uint32_t ly = blockIdx.y * LV + it;
         if (ly >= n_levels) break;                                   // uniform
         const uint32_t level = level_base + ly;
-        uint32_t *cnt = cnt2 + (it & 1u) * NB;
         const LevelMeta m = make_level_meta<3>(offsets, level, H);
         float *__restrict__ gg = grad_table + (size_t)m.offset * C;
+        const bool merging = m.scale * spacing < 0.75f;              // wave-uniform, batch-wide
 
-        // A: rows + values of this thread's eight contributions
-        uint32_t row[8];
-        float val[8][C];
-        float frac[3];
-        uint32_t pg[3];
-        locate<3>(x, m.scale, frac, pg);
-        if (!valid) {
+        // ---- A: records of the thread's points (registers), histogram -------------------------------------------------
+        Rec rec[PTS][4];                                             // the four x-neighbour pairs of a cell
+        uint32_t bkt[PTS][4], lone[PTS][4];                          // lone: row of a second corner that travels alone, or kNoRow
+        bool on[PTS];
 #pragma unroll
-            for (uint32_t ch = 0; ch < C; ++ch) g[ch] = 0.0f;
-        }
-        dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
-            constexpr uint32_t MODE = decltype(mode_tag)::value;
-            float w[8];
-            cell_corners<MODE, 3>(m, frac, pg, w, row);
+        for (uint32_t q = 0; q < PTS; ++q) {
+            uint32_t row[8];
+            float val[8][C];
+            float frac[3];
+            uint32_t pg[3];
+            locate<3>(x[q], m.scale, frac, pg);
+            if (!valid[q]) {
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c)
+                for (uint32_t ch = 0; ch < C; ++ch) g[q][ch] = 0.0f;
+            }
+            dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
+                constexpr uint32_t MODE = decltype(mode_tag)::value;
+                float w[8];
+                cell_corners<MODE, 3>(m, frac, pg, w, row);
 #pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w[c] * g[ch];
-        });
-        // Cells wider than the sample spacing (wave-uniform decision): consecutive samples of a ray that fall into the
-        // same cell hit the same 8 rows.  Merge each run of equal cells with a segmented inclusive scan; only the last
-        // lane of a run emits records.  Runs are cut at 16-lane rows: the scan then moves its operands with DPP row shifts
-        // (a modifier of the VALU instruction) instead of 6 x 16 trips through the LDS crossbar (ds_bpermute) -- on the
-        // three coarse levels that merge, the scan used to cost more than the records it saves (per-level launches:
-        // 0.078 ms against 0.066 ms for a hashed level).  A cut costs at most one extra record set per 16 samples.
-        bool emit = true;
-        if (m.scale * spacing < 0.75f) {
-            const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2];        // merging levels have < 2^16 cells per axis
-            const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
-            const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
-            const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
-            const uint32_t len = lane - start;                               // my position inside the run (same row)
-            auto fold = [&](auto shift_tag) {
-                constexpr uint32_t d = decltype(shift_tag)::value;
-                const float take = len >= d ? 1.0f : 0.0f;          // val += shifted * take: one v_fmac with a DPP operand per value
-#pragma unroll                                                       // (the product with 0 / 1 is exact, so this IS the masked add)
                 for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = __builtin_fmaf(dpp_row_shr<d>(val[c][ch]), take, val[c][ch]);
-            };
-            fold(std::integral_constant<uint32_t, 1>{});
-            fold(std::integral_constant<uint32_t, 2>{});
-            fold(std::integral_constant<uint32_t, 4>{});
-            fold(std::integral_constant<uint32_t, 8>{});
-            emit = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
-        }
-        // take a slot per record and write it; a full bucket (rare: slot_cap = 1.5 x mean + 8) adds straight to the table
-        if (emit) {
-            const uint32_t twist = level_twist(m);                      // wave-uniform
+                    for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w[c] * g[q][ch];
+            });
+            on[q] = true;
+            if (merging) {
+                // Merge each run of equal cells with a segmented inclusive scan; only the last lane of a run emits.  Runs
+                // are cut at 16-lane rows: the scan then moves its operands with DPP row shifts (a modifier of the VALU
+                // instruction) instead of 6 x 16 trips through the LDS crossbar (ds_bpermute).
+                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2];        // merging levels have < 2^16 cells per axis
+                const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
+                const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
+                const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
+                const uint32_t len = lane - start;                               // my position inside the run (same row)
+                auto fold = [&](auto shift_tag) {
+                    constexpr uint32_t d = decltype(shift_tag)::value;
+                    const float take = len >= d ? 1.0f : 0.0f;          // val += shifted * take: the product with 0 / 1 is exact
 #pragma unroll
-            for (uint32_t half = 0; half < 2; ++half) {                 // four corners at a time: fewer live registers
-                uint32_t pos[4], bkt[4];
-                if (twist) {
+                    for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
-                    for (uint32_t c = 0; c < 4; ++c) bkt[c] = bucket_of(row[4 * half + c], plan.log2_nb, 1u);
-                } else {
+                        for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = __builtin_fmaf(dpp_row_shr<d>(val[c][ch]), take, val[c][ch]);
+                };
+                fold(std::integral_constant<uint32_t, 1>{});
+                fold(std::integral_constant<uint32_t, 2>{});
+                fold(std::integral_constant<uint32_t, 4>{});
+                fold(std::integral_constant<uint32_t, 8>{});
+                on[q] = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+            }
+            // x-neighbour corners (2k, 2k+1) travel together when their rows share a 64-row block; otherwise (1.6 % of the
+            // pairs) the record keeps both value halves with mask 0 and phase C splits it into two single records
 #pragma unroll
-                    for (uint32_t c = 0; c < 4; ++c) bkt[c] = bucket_of(row[4 * half + c], plan.log2_nb, 0u);
-                }
-#pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) pos[c] = atomicAdd(&cnt[bkt[c]], 1u);
-#pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    const uint32_t cc = 4 * half + c;
-                    if (pos[c] < CAP) {
-                        Rec r;
-                        r.set(row[cc] >> plan.log2_nb, val[cc]);
-                        staging[bkt[c] * CAP + pos[c]] = r;
-                    } else {
-#pragma unroll
-                        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[cc] * C + ch, val[cc][ch]);
-                        ++n_overflow;
-                    }
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t ra = row[2 * k], rb = row[2 * k + 1], mask = ra ^ rb;
+                const bool paired = mask < 64u;
+                rec[q][k].set(local_of(ra, plan.log2_nb) | (paired ? mask << 16 : 0u), val[2 * k], val[2 * k + 1]);
+                bkt[q][k] = bucket_of(ra, plan.log2_nb);
+                lone[q][k] = paired ? kNoRow : rb;
+                if (on[q]) {
+                    atomicAdd(&hist[bkt[q][k]], 1u);
+                    if (!paired) atomicAdd(&hist[bucket_of(rb, plan.log2_nb)], 1u);
                 }
             }
         }
-        // The next level's gradient is requested here and CONSUMED right after the barrier, before this level's stores are
+        // The next level's gradients are requested here and CONSUMED right after the barrier, before this level's stores are
         // issued: vmcnt retires in order and the compiler can only wait for "everything", so any wait placed after the stores
         // would sit out their whole round trip.  This way the stores drain behind the next level's arithmetic.
-        if (it + 1u < LV && ly + 1u < n_levels) raw_load<FT, C>(grad + ((size_t)(level + 1u) * B + b) * C, graw);
+        if (it + 1u < LV && ly + 1u < n_levels) {
+#pragma unroll
+            for (uint32_t q = 0; q < PTS; ++q) raw_load<FT, C>(grad + ((size_t)(level + 1u) * B + bp[q]) * C, graw[q]);
+        }
         lds_barrier();
-        raw_unpack<FT, C>(graw, g);
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ++ch) asm volatile("" : "+v"(g[ch]) : : "memory");      // pin the wait here
+        for (uint32_t q = 0; q < PTS; ++q) {
+            raw_unpack<FT, C>(graw[q], g[q]);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ++ch) asm volatile("" : "+v"(g[q][ch]) : : "memory");      // pin the wait here
+        }
 
-        // B: copy each bucket run to its region.  A wave owns buckets wave, wave+NW, ...; it takes them kCopy at a time
-        //    with straight-line code (run lengths, then staging reads, then stores) so the LDS / global round trips of
-        //    several buckets overlap.  8-byte records travel two per lane as 16-byte LDS reads / global stores
-        //    (slot_cap even, <= 128).  The other counter set is cleared for the next level meanwhile.
-        for (uint32_t i = threadIdx.x; i < NB; i += NT) cnt2[((it & 1u) ^ 1u) * NB + i] = 0u;
-        if constexpr (sizeof(Rec) == 8) {
-            constexpr uint32_t kCopy = 4;                              // NB (>= 64, a power of two) is a multiple of NW * kCopy
-            const uint32_t pairs = CAP >> 1;
-            const uint32_t my_pair = min(lane, pairs - 1u);     // (slot_cap is a multiple of 16 records = 128 B here)
-            Rec *__restrict__ tile_regions = regions + region_index(plan, ly, 0u, tile) * CAP;      // the NB regions of this tile are adjacent
-            for (uint32_t base = wave; base < NB; base += NW * kCopy) {
-                uint32_t nrun[kCopy];
-                uint4 v[kCopy];
+        // ---- B: histogram -> exclusive offsets (wave 0: NB / 64 consecutive buckets per lane), run words, total --------
+        if (wave == 0u) {
+            const uint32_t per = NB >> 6;                                // 1 for 64 buckets, 8 for 512
+            uint32_t mine = 0u;
+            for (uint32_t j = 0; j < per; ++j) mine += hist[lane * per + j];
+            uint32_t incl = mine;
 #pragma unroll
-                for (uint32_t k = 0; k < kCopy; ++k) nrun[k] = min(cnt[base + NW * k], CAP);
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            uint32_t run_start = incl - mine;
+            for (uint32_t j = 0; j < per; ++j) {
+                const uint32_t b = lane * per + j, n = hist[b];
+                cursor[b] = run_start;
+                hist[b] = 0u;                                            // ready for the next level
+                const uint32_t start_c = min(run_start, SLOTS), n_c = min(n, SLOTS - start_c);      // what fits the block
+                runs[run_index(plan, ly, b, tile)] = start_c | (n_c << 16);
+                run_start += n;
+            }
+            if (lane == 63u) total_p[0] = incl;
+        }
+        lds_barrier();
+
+        // ---- C: placement -------------------------------------------------------------------------------------------------
+        auto place = [&](uint32_t b, const uint32_t (&words)[K], uint32_t row_a, uint32_t row_b, const Rec &r) {
+            const uint32_t pos = atomicAdd(&cursor[b], 1u);
+            if (pos < SLOTS) {
+                uint32_t *dst = staging + (size_t)pos * K;
 #pragma unroll
-                for (uint32_t k = 0; k < kCopy; ++k)
-                    v[k] = reinterpret_cast<const uint4 *>(staging + (base + NW * k) * CAP)[my_pair];
+                for (uint32_t i = 0; i < K; ++i) dst[i] = words[i];
+            } else {                                                     // the tile's block is full (see the header): straight to the table
 #pragma unroll
-                for (uint32_t k = 0; k < kCopy; ++k)
-                    if (2u * lane < min((nrun[k] + 15u) & ~15u, CAP))        // whole 128-byte lines; stale slots are harmless
-                        reinterpret_cast<uint4 *>(tile_regions + (size_t)(base + NW * k) * CAP)[lane] = v[k];
-                // the kCopy run lengths of the batch leave with ONE store: lane k writes the count of bucket base + NW k
-                if (lane < kCopy) {
-                    uint32_t mine = nrun[0];
+                for (uint32_t ch = 0; ch < C; ++ch) {
+                    atomicAdd(gg + (size_t)row_a * C + ch, r.value(0, ch));
+                    if (row_b != row_a) atomicAdd(gg + (size_t)row_b * C + ch, r.value(1, ch));
+                }
+                ++n_overflow;
+                ++n_overflow_level;
+            }
+        };
 #pragma unroll
-                    for (uint32_t k = 1; k < kCopy; ++k) mine = lane == k ? nrun[k] : mine;
-                    counts[count_index(plan, ly, base + NW * lane, tile)] = mine;
+        for (uint32_t q = 0; q < PTS; ++q) {
+            if (!on[q]) continue;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const Rec &r = rec[q][k];
+                const uint32_t la = r.w[0] & 0xffffu;
+                const uint32_t row_a = row_of(bkt[q][k], la, plan.log2_nb);
+                if (lone[q][k] == kNoRow) {
+                    place(bkt[q][k], r.w, row_a, row_of(bkt[q][k], la ^ (r.w[0] >> 16), plan.log2_nb), r);
+                } else {                                                  // two single records: first corner, second corner
+                    Rec a = r, b2;
+                    float va[C], vb[C], zero[C];
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) { va[ch] = r.value(0, ch); vb[ch] = r.value(1, ch); zero[ch] = 0.0f; }
+                    a.set(la, va, zero);
+                    b2.set(local_of(lone[q][k], plan.log2_nb), vb, zero);
+                    place(bkt[q][k], a.w, row_a, row_a, a);
+                    place(bucket_of(lone[q][k], plan.log2_nb), b2.w, lone[q][k], lone[q][k], b2);
                 }
             }
-        } else {
-            for (uint32_t bkt = wave; bkt < NB; bkt += NW) {
-                const uint32_t n = min(cnt[bkt], CAP);
-                const size_t reg = region_index(plan, ly, bkt, tile);
-                Rec *__restrict__ dst = regions + reg * CAP;
-                for (uint32_t slot = lane; slot < n; slot += 64u) dst[slot] = staging[bkt * CAP + slot];
-                if (lane == 0u) counts[count_index(plan, ly, bkt, tile)] = n;
-            }
         }
-        lds_barrier();                                               // staging and this counter set are free again
+        lds_barrier();
+
+        // ---- D: the dense block leaves as whole 128-byte lines (16 bytes per lane; stale slots past the end are harmless) -----
+        {
+            const uint32_t n_rec = min(total_p[0], SLOTS);
+            const uint32_t n_chunk = min(((n_rec * (uint32_t)sizeof(Rec) + 127u) >> 7) << 3, (SLOTS * (uint32_t)sizeof(Rec)) >> 4);
+            uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(blocks + block_index(plan, ly, tile));
+            const uint4 *from = reinterpret_cast<const uint4 *>(staging);
+            for (uint32_t c = threadIdx.x; c < n_chunk; c += NT) dst[c] = from[c];
+        }
+        if (__ballot(n_overflow_level != 0u)) {                          // diagnostics: overflow per level (overflow[1 + level])
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) n_overflow_level += __shfl_xor(n_overflow_level, off, 64);
+            if (lane == 0u) atomicAdd(overflow + 1u + level, n_overflow_level);
+            n_overflow_level = 0u;
+        }
+        // no barrier here: the next level touches only `hist` (cleared in B) before its own first barrier, and writes the
+        // staging block after its second one -- every wave has finished this copy before it arrives at the first.
     }
     if (__ballot(n_overflow != 0u)) {                                // statistics only: one atomic per wave that overflowed
 #pragma unroll
@@ -303,43 +376,44 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 // Accumulators are 64-bit FIXED POINT updated with ds_add_u64: integer LDS atomics run at 4.7 lane-ops/clk/CU on
 // gfx950 against 2.46 for ds_add_f64 and 0.33 for ds_add_f32 (tools/lds_atomic_bench.hip).  Integer addition is
 // associative, so the reduction is bit-reproducible from run to run.  The scale follows the largest feature gradient of
-// the step (fixed_shift): 31 significant bits below it, 26 bits of headroom above for the sum of merged records.
+// the step (fixed_shift): 31 significant bits below it, 28 bits of headroom above for the sum of merged records.
 template <uint32_t C, typename Rec>
 __global__ void __launch_bounds__(1024)
-scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
-                      float *__restrict__ grad_table, float *__restrict__ sums, const uint32_t *__restrict__ gmax_bits,
-                      uint32_t H, uint32_t level_base, uint32_t ly_begin, BinPlan plan) {
+scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
+                      float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base,
+                      uint32_t ly_begin, BinPlan plan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift(gbits);
     const bool poison = fixed_nonfinite(gbits);
     const double scale = ldexp(1.0, shift);
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
-    const uint32_t T_ = blockDim.x, CAP = plan.slot_cap;
+    const uint32_t T_ = blockDim.x;
     const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
     const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
-    // rows of this bucket: one per complete group of NB rows, plus one if the bucket's row of the last, partial group exists
-    const uint32_t full_groups = T >> plan.log2_nb;
-    const uint32_t twist = level_twist(make_level_meta<3>(offsets, level, H));
-    const uint32_t rows_local = full_groups + (row_of(bucket, full_groups, plan.log2_nb, twist) < T ? 1u : 0u);
+    const uint32_t rows_local = local_rows(T, plan.log2_nb);
     // accumulators are channel-major, acc[ch][local row]: the two 8-byte cells of a row would otherwise sit 8 bytes apart and
     // one ds_add_u64 instruction (one channel of 64 rows) could reach only every other bank pair
     const uint32_t pitch = plan.max_local_rows;
     for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
-    // the wave index is made scalar explicitly: tile ranges, run-length block addresses and region bases then live in SGPRs
+    // the wave index is made scalar explicitly: tile ranges, run-word addresses and block bases then live in SGPRs
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = T_ >> 6;
-    const size_t cnt0 = count_index(plan, ly, bucket, 0);
-    auto add = [&](const Rec &r) {
+    const size_t run0 = run_index(plan, ly, bucket, 0);
+    auto add = [&](const Rec &r) {          // both halves unconditionally: a record without a second corner adds zeros to its own row
+        const uint32_t la = r.w[0] & 0xffffu, lb = la ^ (r.w[0] >> 16);
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&acc[ch * pitch + r.w[0]], (unsigned long long)to_fixed(r.value(ch), scale));   // ds_add_u64
+        for (uint32_t ch = 0; ch < C; ++ch) {
+            atomicAdd(&acc[ch * pitch + la], (unsigned long long)to_fixed(r.value(0, ch), scale));   // ds_add_u64
+            atomicAdd(&acc[ch * pitch + lb], (unsigned long long)to_fixed(r.value(1, ch), scale));
+        }
     };
-    // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run lengths.  Regions are read
-    // kGroup at a time with straight-line code: kGroup loads for records 0..63 plus kGroup * kTail / 64 loads for the tails
-    // are in flight per lane before the first LDS atomic (lanes past a run length read slot 0, a line that is fetched
-    // anyway -> no extra traffic).
-    constexpr uint32_t kGroup = 8, kTail = 16;
+    // each wave owns blocks of 64 consecutive tiles: one coalesced load brings their run words.  Runs are read kGroup at a
+    // time with straight-line code: kGroup loads for records 0..63 plus kGroup * kTail / 64 loads for the tails are in
+    // flight per lane before the first LDS atomic (lanes past a run's end read its first record, a line that is fetched
+    // anyway -> no extra traffic); whatever a run holds beyond 64 + kTail records follows in a plain loop.
+    constexpr uint32_t kGroup = sizeof(Rec) <= 12 ? 8u : 4u, kTail = 32;
     // every wave streams ONE contiguous range of tiles
     // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
     const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
@@ -347,32 +421,38 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
     const uint32_t per_wave = (((split_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
     const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
-        const uint32_t mine = t0 + lane < t_end ? counts[cnt0 + t0 + lane] : 0u;
+        const uint32_t mine = t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u;
         const uint32_t n_here = min(64u, t_end - t0);
         for (uint32_t j = 0; j < n_here; j += kGroup) {
             uint32_t n[kGroup], n_max = 0u;
+            const Rec *base[kGroup];
             Rec ra[kGroup];
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) {
                 const uint32_t tj = min(j + u, n_here - 1u);
-                n[u] = j + u < n_here ? (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)tj) : 0u;      // scalar (tj is wave-uniform)
+                const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)tj);              // scalar (tj is wave-uniform)
+                n[u] = j + u < n_here ? word >> 16 : 0u;
                 n_max = max(n_max, n[u]);
-                ra[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane < n[u] ? lane : 0u];
+                base[u] = blocks + block_index(plan, ly, t0 + tj) + (word & 0xffffu);
+                ra[u] = base[u][lane < n[u] ? lane : 0u];
             }
-            if (n_max <= 64u + kTail) {
-                // the usual case: no run is longer than 64 + kTail records.  The tails (records 64..) of 64 / kTail regions
-                // share one load and one pair of LDS atomics, kTail lanes per region, instead of a nearly empty wave each.
-                constexpr uint32_t kPer = 64u / kTail;                      // regions per tail instruction
+            {
+                // The tails (records 64 .. 64 + kTail) of 64 / kTail runs share one load and one set of LDS atomics, kTail lanes
+                // per run, instead of a nearly empty wave each.
+                constexpr uint32_t kPer = 64u / kTail;                      // runs per tail instruction
                 Rec rt[kGroup / kPer];
                 uint32_t nt[kGroup / kPer];
 #pragma unroll
                 for (uint32_t q = 0; q < kGroup / kPer; ++q) {
-                    const uint32_t sub = lane / kTail, u = q * kPer + sub, slot = 64u + (lane % kTail);
-                    const uint32_t tj = min(j + u, n_here - 1u);
-                    nt[q] = n[q * kPer];                                    // select among the kPer scalar run lengths
+                    const uint32_t sub = lane / kTail, slot = 64u + (lane % kTail);
+                    nt[q] = n[q * kPer];                                    // select among the kPer scalar run lengths / bases
+                    const Rec *bq = base[q * kPer];
 #pragma unroll
-                    for (uint32_t k = 1; k < kPer; ++k) nt[q] = sub == k ? n[q * kPer + k] : nt[q];
-                    rt[q] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[slot < nt[q] ? slot : 0u];
+                    for (uint32_t k = 1; k < kPer; ++k) {
+                        nt[q] = sub == k ? n[q * kPer + k] : nt[q];
+                        bq = sub == k ? base[q * kPer + k] : bq;
+                    }
+                    rt[q] = bq[slot < nt[q] ? slot : 0u];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kGroup; ++u)
@@ -380,68 +460,32 @@ scatter_reduce_kernel(const Rec *__restrict__ regions, const uint32_t *__restric
 #pragma unroll
                 for (uint32_t q = 0; q < kGroup / kPer; ++q)
                     if (64u + (lane % kTail) < nt[q]) add(rt[q]);
-            } else {
-                Rec rb[kGroup];                                             // slot_cap <= 128 (planner invariant): two loads
-#pragma unroll                                                              // per lane cover a whole region
-                for (uint32_t u = 0; u < kGroup; ++u) {
-                    const uint32_t tj = min(j + u, n_here - 1u);
-                    rb[u] = (regions + region_index(plan, ly, bucket, t0 + tj) * CAP)[lane + 64u < n[u] ? lane + 64u : 0u];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u) {
-                    if (lane < n[u]) add(ra[u]);
-                    if (lane + 64u < n[u]) add(rb[u]);
-                }
+            }
+            if (n_max > 64u + kTail) {                                      // long runs (clustered tiles): the rest, run by run
+#pragma unroll 1
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    for (uint32_t i = 64u + kTail + lane; i < n[u]; i += 64u) add(base[u][i]);
             }
         }
     }
     __syncthreads();
+    float *__restrict__ gg = grad_table + (size_t)off * C;
+    const float nan = __builtin_nanf("");
     if (gridDim.z == 1u) {
-        // sole owner of these rows, but they are NB rows apart in the table: write the finished sums as one contiguous block
-        // [level][bucket][local][C]; scatter_apply_kernel adds them to the table with coalesced accesses on both sides
-        float *__restrict__ dst = sums + (((size_t)ly << plan.log2_nb) + bucket) * sums_rows(plan) * C;
+        // sole owner, and the bucket's local rows 64 k .. 64 k + 63 are 64 consecutive table rows: add the sums in place,
+        // coalesced (64 x C floats per block)
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            dst[i] = poison ? __builtin_nanf("") : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
+            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            if (row < T) gg[(size_t)row * C + ch] += poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
         }
     } else {
-        float *__restrict__ gg = grad_table + (size_t)off * C;
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            atomicAdd(gg + (size_t)row_of(bucket, local, plan.log2_nb, twist) * C + ch,
-                      poison ? __builtin_nanf("") : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));   // one add per row and split
-        }
-    }
-}
-
-// ---- pass 3 ---------------------------------------------------------------------------------------------------
-// grad_table[row] += sums[level][bucket][local] for row = row_of(bucket, local).  One workgroup = 64 local rows x 64
-// buckets: the block is read bucket-major (64 local rows x C floats contiguous per bucket), turned in LDS and added to
-// the table row-major (the 64 buckets of one local row are 64 consecutive rows, in rotated order).  Doing this
-// read-modify-write straight from the reducer touches every 64-byte sector of the table for 8 useful bytes.
-template <uint32_t C>
-__global__ void __launch_bounds__(256)
-scatter_apply_kernel(const float *__restrict__ sums, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
-                     uint32_t H, uint32_t level_base, uint32_t ly_begin, BinPlan plan) {
-    __shared__ float tile[64][64 * C + 1];                      // [bucket in group][local in block][C], odd pitch
-    const uint32_t ly = ly_begin + blockIdx.y, level = level_base + ly, local0 = blockIdx.x * 64u, bucket0 = blockIdx.z * 64u;
-    const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
-    if (((size_t)local0 << plan.log2_nb) >= T) return;          // block past the end of this level (uniform)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const size_t rows = sums_rows(plan);
-    const uint32_t twist = level_twist(make_level_meta<3>(offsets, level, H));
-    for (uint32_t b = wave; b < 64u; b += 4u) {
-        const float *src_b = sums + ((((size_t)ly << plan.log2_nb) + bucket0 + b) * rows + local0) * C;
-#pragma unroll
-        for (uint32_t k = 0; k < C; ++k) tile[b][lane + 64u * k] = src_b[lane + 64u * k];      // element e = local * C + ch
-    }
-    __syncthreads();
-    float *__restrict__ gg = grad_table + (size_t)off * C;
-    for (uint32_t j = wave; j < 64u; j += 4u) {
-        const uint32_t row = row_of(bucket0 + lane, local0 + j, plan.log2_nb, twist);
-        if (row < T) {
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ++ch) gg[(size_t)row * C + ch] += tile[lane][j * C + ch];
+            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            if (row < T)
+                atomicAdd(gg + (size_t)row * C + ch,
+                          poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));   // one add per row and split
         }
     }
 }

@@ -215,6 +215,16 @@ class NAFEngine:
                    "scatter_overflow_count")
         return int(out.value)
 
+    def scatter_overflow_levels(self, n_rays):
+        """Diagnostic: the same per level (list of num_levels counts; synchronises)."""
+        cfg = self._cfg()
+        n_points = n_rays * self.n_samples
+        ws = fused.workspace(cfg, n_points, self.device)
+        out = (ctypes.c_uint32 * 32)()
+        _abi.check(_abi.lib().naf_scatter_overflow_levels(ctypes.byref(cfg), n_points, _abi.ptr(ws), ctypes.byref(out)),
+                   "scatter_overflow_levels")
+        return [int(v) for v in out][:self.net.encoder.num_levels]
+
     def all_reduce_grads(self):
         """Single-buffer form (one all-reduce of table + MLP gradients + loss); the training step uses the bucketed,
         overlapped form below.  Kept for callers that fill the gradient buffers themselves."""
