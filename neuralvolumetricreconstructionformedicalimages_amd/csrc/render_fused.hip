@@ -776,6 +776,10 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     // on top never fills up in practice, and a tile that does fill it spills to atomics (still correct).  A multiple of 32
     // records: blocks start on 128-byte lines whatever the record size.
     plan->slots = std::min<uint32_t>(65504u, ((tile * 5u) + 31u) & ~31u);
+    // pass 2 reads a bucket's run of a tile with W lanes: W = the power of two >= 1.25 x the mean run length, at most a wave
+    const uint32_t mean_run = std::max<uint32_t>(1u, (tile * 4u) >> log2_nb);
+    plan->log2_w = 3u;
+    while (plan->log2_w < 6u && (1u << plan->log2_w) < mean_run + mean_run / 4u) ++plan->log2_w;
     plan->max_local_rows = (uint32_t)((((maxT + (1ull << log2_nb) - 1) >> log2_nb) + 63u) & ~63ull);
     const size_t per_level = (size_t)plan->n_tiles * plan->slots * rec;
     plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));

@@ -95,6 +95,7 @@ struct BinPlan {
     uint32_t slots;           // records per (level, tile) block = LDS staging slots of pass 1 (a multiple of 32, < 2^16)
     uint32_t levels_per_pass;
     uint32_t max_local_rows;  // ceil(max T_l / NB), rounded up to a multiple of 64
+    uint32_t log2_w;          // pass 2: lanes per run (6: a whole wave per run; less when many buckets make the runs short)
 };
 
 // Pass-1 shape by record size (compile time): 12-byte records (two bf16 channels) get 512 threads x 2 points -- 1024-point
@@ -420,6 +421,36 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
     const uint32_t per_wave = (((split_tiles + n_waves - 1u) / n_waves) + 63u) & ~63u;
     const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
+    if (plan.log2_w < 6u) {
+        // Many buckets (T >= 2^20: 128 .. 512 per level) make the runs short -- 8 to 32 records: a wave takes G = 64 / W runs per
+        // instruction, W lanes each, four instructions' worth of loads in flight; whatever a run holds beyond W follows in a loop.
+        const uint32_t W = 1u << plan.log2_w, G = 64u >> plan.log2_w, g = lane >> plan.log2_w, j = lane & (W - 1u);
+        constexpr uint32_t kSteps = 4;
+        for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
+            const uint32_t mine = t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u;
+            const uint32_t n_here = min(64u, t_end - t0);
+            for (uint32_t s0 = 0; s0 < n_here; s0 += kSteps * G) {
+                uint32_t n4[kSteps];
+                const Rec *b4[kSteps];
+                Rec r4[kSteps];
+#pragma unroll
+                for (uint32_t u = 0; u < kSteps; ++u) {
+                    const uint32_t tl = s0 + u * G + g;
+                    const uint32_t word = (uint32_t)__shfl((int)mine, (int)min(tl, 63u), 64);
+                    n4[u] = tl < n_here ? word >> 16 : 0u;
+                    b4[u] = blocks + block_index(plan, ly, t0 + min(tl, n_here - 1u)) + (word & 0xffffu);
+                    r4[u] = b4[u][j < n4[u] ? j : 0u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSteps; ++u)
+                    if (j < n4[u]) add(r4[u]);
+#pragma unroll 1
+                for (uint32_t u = 0; u < kSteps; ++u)
+                    for (uint32_t i = W + j; __ballot(i < n4[u]) != 0ull; i += W)
+                        if (i < n4[u]) add(b4[u][i]);
+            }
+        }
+    } else
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
         const uint32_t mine = t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u;
         const uint32_t n_here = min(64u, t_end - t0);
