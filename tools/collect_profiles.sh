@@ -1,31 +1,45 @@
 #!/bin/bash
 # Collects the evidence kept under profiles/ on the GPU box (run through gpurun from the repo root):
 #   rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE counter passes (separate runs), the default bench line, a batch
-#   sweep, the fp32 mode and the per-level split.  Everything lands in gpurun_out/prof/; tools/install_profiles.py copies
+#   sweep, the fp32 mode, the per-level split, the data-parallel step on one GPU, evaluation and train.py throughput,
+#   other BASELINE shapes and the chest PSNR curves.  Everything lands in gpurun_out/prof/; tools/install_profiles.py copies
 #   the summaries into profiles/.
 set -e
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--steps 10 --warmup 2 --rays 65536 --cpu-seconds 0"
+ARGS="--steps 10 --warmup 2 --rays 65536 --cpu-seconds 0 --sub-records 0"
+PMC="--steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo stats done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_fetch.json 2> $OUT/fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py $PMC > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo fetch done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_write.json 2> $OUT/write.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py $PMC > $OUT/bench_write.json 2> $OUT/write.err
 echo write done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/mfma -o mfma -- python3 bench.py --steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_mfma.json 2> $OUT/mfma.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/mfma -o mfma -- python3 bench.py $PMC > $OUT/bench_mfma.json 2> $OUT/mfma.err
 echo mfma done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_sqa.json 2> $OUT/sqa.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 > $OUT/bench_sqb.json 2> $OUT/sqb.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0 > $OUT/bench_sqa.json 2> $OUT/sqa.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0 > $OUT/bench_sqb.json 2> $OUT/sqb.err
 echo sq done
-timeout -k 10 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo default done
 for r in 128 1024 4096 16384 65536 262144 1048576; do
-  timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays $r --cpu-seconds 0 >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
+  timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays $r --cpu-seconds 0 --sub-records 0 >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
 done
 echo sweep done
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
-timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 --sub-records 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
+timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 --sub-records 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
+timeout -k 10 300 python bench.py --force-dp --steps 10 --warmup 3 --cpu-seconds 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
+echo modes done
+timeout -k 10 200 python tools/eval_bench.py > $OUT/eval.jsonl 2> $OUT/eval.err
+timeout -k 10 200 python tools/eval_bench.py --precision fp32 >> $OUT/eval.jsonl 2>> $OUT/eval.err
+timeout -k 10 300 python tools/train_throughput.py > $OUT/train_py.json 2> $OUT/train_py.err
+for a in "--log2T 22 --samples 320 --table fp16 --rays 32768" "--log2T 21 --samples 192 --table bf16 --rays 32768" "--log2T 20 --samples 192 --table bf16 --rays 65536" "--log2T 19 --samples 576 --table bf16 --rays 16384" "--log2T 19 --samples 192 --table bf16 --rays 65536"; do
+  timeout -k 10 100 python tools/step_bench.py $a 2>> $OUT/shapes.err | tail -n 1 >> $OUT/shapes.jsonl
+done
+echo eval + shapes done
+timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --out $OUT/psnr_16384_bf16.json > $OUT/psnr_a.log 2>&1
+timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --precision fp32 --out $OUT/psnr_16384_fp32.json > $OUT/psnr_b.log 2>&1
+timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-every 5000 --out $OUT/psnr_1024_bf16.json > $OUT/psnr_c.log 2>&1
 echo all done
 find $OUT -name "*.csv" | head -20

@@ -24,6 +24,12 @@ copy("bench_default.json", f"{TAG}_bench_default.json")
 copy("batch_sweep.jsonl", f"{TAG}_batch_sweep.jsonl")
 copy("bench_fp32_16384.json", f"{TAG}_bench_fp32_16384rays.json")
 copy("bench_per_level_16384.json", f"{TAG}_bench_per_level_16384rays.json")
+for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"), ("eval.jsonl", "eval_throughput.jsonl"),
+                 ("train_py.json", "train_py_throughput.json"), ("shapes.jsonl", "other_shapes_step_times.jsonl"),
+                 ("psnr_16384_bf16.json", "chest_psnr_vs_time_16384rays.json"), ("psnr_16384_fp32.json", "chest_psnr_vs_time_16384rays_fp32.json"),
+                 ("psnr_1024_bf16.json", "chest_psnr_vs_time_1024rays.json")):
+    if os.path.exists(os.path.join(SRC, src)):
+        copy(src, f"{TAG}_{dst}")
 
 per_dispatch = os.path.join(DST, f"{TAG}_pmc_bytes_per_dispatch.json")
 subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"),
@@ -77,7 +83,7 @@ def counters(*files):
 
 sq = counters("sqa/sqa_counter_collection.csv", "sqb/sqb_counter_collection.csv")
 mf = counters("mfma/mfma_counter_collection.csv")
-kernels = ("encode_kernel", "mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "scatter_apply_kernel")
+kernels = ("encode_kernel", "mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "draw_scan_rays_kernel", "adam_kernel")
 out = ["# Counter evidence per kernel (MI355X, chest_50 bf16, 65 536 rays/step = 12.58 M points; tools/collect_profiles.sh)", "",
        "## Dynamic instruction mix", "",
        "`rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0`,",
