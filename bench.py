@@ -137,6 +137,10 @@ class ScanSampler:
 
 
 def main():
+    # ONE JSON line on stdout: libraries that print to file descriptor 1 (RCCL's version banner at the first collective) are
+    # sent to stderr for the whole run; the result line is written to the real stdout at the end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -385,7 +389,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0 and not args.force_dp:
             log("cpu_baseline leg (oracle, host cores)")
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if pg is not None:
         torch.distributed.destroy_process_group()
 

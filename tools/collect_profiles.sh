@@ -42,4 +42,7 @@ timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-e
 timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --precision fp32 --out $OUT/psnr_16384_fp32.json > $OUT/psnr_b.log 2>&1
 timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-every 5000 --out $OUT/psnr_1024_bf16.json > $OUT/psnr_c.log 2>&1
 echo all done
-find $OUT -name "*.csv" | head -20
+# summarise on the box and keep only the summaries (the kernel traces alone exceed what gpurun copies back)
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round2}
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/sqa $OUT/sqb
+ls gpurun_out/profiles_staged
