@@ -252,6 +252,15 @@ int naf_render_train_bucketed(const float *rays, const float *t_rand, const floa
 int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,
                       float *sigma, uint32_t B, const naf_render_cfg *cfg, void *workspace, void *stream);
 
+/* The same on a regular grid that is generated instead of read (the volume query of train.py:246-250 on the voxel grid
+ * of tigre.py:388-400): axis k holds dims[k] values numpy.linspace(start[k], stop[k], dims[k]) (float64, cast to float32
+ * like the dataset does), sigma is [dims[0], dims[1], dims[2]] in 'ij' order.  Bit-identical to naf_field_forward on the
+ * materialised grid; the kernel walks the grid with axis 0 fastest, which turns most gathers of the hashed levels into L1
+ * hits.  start / stop / dims are HOST arrays of three; the grid must lie inside [-bound, bound]. */
+int naf_field_forward_grid(const double *start, const double *stop, const uint32_t *dims, const void *embeddings,
+                           const int32_t *offsets, const float *mlp, float *sigma, const naf_render_cfg *cfg, void *workspace,
+                           void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * T4  Adam (torch.optim.Adam semantics, trainer.py:54: lr, betas=(0.9,0.999), eps=1e-8, no weight decay,
  * amsgrad off).  `step` is the 1-based step count.  If param_lp != NULL a low-precision copy of the

@@ -85,6 +85,8 @@ SIGNATURES = {
     "naf_render_train_bucketed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
                                          ctypes.POINTER(GradBuckets), _vp]),
     "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_field_forward_grid": (_i32, [ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(ctypes.c_double * 3),
+                                      ctypes.POINTER(ctypes.c_uint32 * 3), _vp, _vp, _vp, _vp, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _u64, _f32, _f32, _f32, _f32, _u32, _f32, _i32, _vp]),
     "naf_normalize_inputs": (_i32, [_vp, _u64, _f32, _vp, _vp, _vp]),
 }

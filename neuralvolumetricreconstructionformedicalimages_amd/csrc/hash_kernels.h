@@ -53,6 +53,42 @@ struct SrcRaw {
     }
 };
 
+// (b') points of a regular grid, generated instead of read: axis k has n[k] values np.linspace(start[k], stop[k], n[k])
+//      (tigre.py:388-400 builds the voxel grid that way, in float64, and the dataset casts it to float32).  The traversal is
+//      axis 0 FASTEST, then axis 2, then axis 1: the 64 points of a wave are neighbours along x, whose rows share 64-row
+//      blocks on the hashed levels (r = x ^ h(y,z)), so their gathers hit the same few lines -- the volume query of
+//      train.py:246-250 reads the table through L1 instead of missing it with every corner.
+struct SrcGrid {
+    static constexpr bool kInRange = false;
+    double start[3], step[3], stop[3];
+    uint32_t n[3];
+    float bound;
+    // internal point index -> grid indices (axis 0 fastest, then 2, then 1)
+    __device__ __forceinline__ void index(uint32_t b, uint32_t (&i)[3]) const {
+        i[0] = b % n[0];
+        const uint32_t rest = b / n[0];
+        i[2] = rest % n[2];
+        i[1] = rest / n[2];
+    }
+    // position in the caller's [n0, n1, n2] array (axis 2 fastest, 'ij' meshgrid order)
+    __device__ __forceinline__ size_t flat(uint32_t b) const {
+        uint32_t i[3];
+        index(b, i);
+        return ((size_t)i[0] * n[1] + i[1]) * n[2] + i[2];
+    }
+    __device__ __forceinline__ void get(uint32_t b, float (&out)[3]) const {
+        uint32_t i[3];
+        index(b, i);
+        const float denom = 2.0f * bound, rden = 1.0f / denom;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) {
+            // numpy.linspace: start + i * step in float64 (a multiply and an add), the last value is `stop` itself
+            const double v = i[d] + 1u == n[d] && n[d] > 1u ? stop[d] : __dadd_rn(__dmul_rn((double)i[d], step[d]), start[d]);
+            out[d] = div_exact((float)v + bound, denom, rden);
+        }
+    }
+};
+
 // (c) sample s of ray r (b = r*S + s): stratified depth, point on ray, clamp, normalise
 //     (render.py:87-105 + hashgrid.py:125) -- nothing [B,3]-sized ever touches HBM.
 struct SrcRays {

@@ -138,13 +138,24 @@ __device__ __forceinline__ float emit_samples(float term, float sigma, float car
     return __shfl(scan, W - 1u, W);          // the tile's last sample carries the total so far (lanes past S add 0)
 }
 
+// Where point p of a point-list launch writes its output: identity, or (grid queries, SrcGrid traversal) the position of
+// grid point p in the caller's [n0, n1, n2] array.
+struct OutMap {
+    uint32_t n0, n1, n2;          // n0 == 0: identity
+    __device__ __forceinline__ size_t at(uint32_t p) const {
+        if (n0 == 0u) return p;
+        const uint32_t i0 = p % n0, rest = p / n0, i2 = rest % n2, i1 = rest / n2;
+        return ((size_t)i0 * n1 + i1) * n2 + i2;
+    }
+};
+
 // ---- 2: MLP forward + line integral ----------------------------------------------------------------------
 // kRays: one wave per ray, acc[r] = sum_s sigma*dist.   !kRays: plain point list, out[p] = sigma(p).
 template <typename P, uint32_t C, bool kRays>
 __global__ void __launch_bounds__(256, 3)
 mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                    float *__restrict__ out, float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items,
-                   uint32_t B, int act) {
+                   uint32_t B, int act, OutMap omap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MlpShared<P>::build(smem, mlp, 4);
     const uint32_t lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
@@ -194,7 +205,7 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
             const uint32_t p = valid ? p0 : n_items - 1u;
             load_feat_slots<typename P::feat_t, C>(feat, B, p, h, x0);
             const float z4 = mlp_tile_forward<P>(smem, lane, x0, x0f, h1, h2, h3);
-            if (valid && h == 0) out[p] = last_act(act, z4);
+            if (valid && h == 0) out[omap.at(p)] = last_act(act, z4);
         }
     }
 }
@@ -203,7 +214,8 @@ mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const f
 template <bool kRays>
 __global__ void __launch_bounds__(256, 4)
 mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src, float *__restrict__ out,
-                     float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items, uint32_t B, int act) {
+                     float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items, uint32_t B, int act,
+                     OutMap omap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Mlp16Shared::build(smem, mlp, 4);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
@@ -252,7 +264,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             Feat16Raw raw;
             load_feat16(feat, B, p, g, raw);
             const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(raw), a);
-            if (valid && g == 0u) out[p] = last_act(act, z4);
+            if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
         }
     }
 }
@@ -772,10 +784,15 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
-    // A tile's block holds four pair records per point plus the second halves of unpaired pairs (1.6 % on average): a quarter
-    // on top never fills up in practice, and a tile that does fill it spills to atomics (still correct).  A multiple of 32
-    // records: blocks start on 128-byte lines whatever the record size.
-    plan->slots = std::min<uint32_t>(65504u, ((tile * 5u) + 31u) & ~31u);
+    // A tile's block holds four pair records per point plus the second halves of unpaired pairs (1.6 % on average, but ALL
+    // pairs of a ray that keeps an x cell with index 63 mod 64 for its whole length): as many slots as let two pass-1
+    // workgroups share a CU's 160 KB of LDS (1.6x for 12-byte records), at least 1.25x.  A tile that still fills its block
+    // spills the excess to atomics (correct, counted).  A multiple of 32 records: blocks start on 128-byte lines.
+    {
+        const size_t lds_half = ((size_t)80 << 10) - (2u * ((size_t)1 << log2_nb) + 4u) * 4u;
+        const uint32_t fit = (uint32_t)(lds_half / rec) & ~31u, least = ((tile * 5u) + 31u) & ~31u;
+        plan->slots = std::min<uint32_t>(65504u, std::max(least, std::min(fit, tile * 8u)));
+    }
     // pass 2 reads a bucket's run of a tile with W lanes: W = the power of two >= 1.25 x the mean run length, at most a wave
     const uint32_t mean_run = std::max<uint32_t>(1u, (tile * 4u) >> log2_nb);
     plan->log2_w = 3u;
@@ -908,14 +925,15 @@ static int dispatch_encode(const Src &src, const void *table, const int32_t *off
 
 template <typename P, uint32_t C, bool kRays>
 static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &src, float *out, uint32_t n_items, uint32_t B,
-                           const naf_render_cfg *cfg, hipStream_t s, float *sigma_out = nullptr, float *depth_out = nullptr) {
+                           const naf_render_cfg *cfg, hipStream_t s, float *sigma_out = nullptr, float *depth_out = nullptr,
+                           OutMap omap = OutMap{0u, 0u, 0u}) {
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
         {
             const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u;
             const uint64_t waves16 = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves16 + 3) / 4, 256u * 8u));
             { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL((mlp16_forward_kernel<kRays>), dim3(grid16), dim3(256), lds16, s,
-                               (const uint16_t *)feat, mlp, src, out, sigma_out, depth_out, n_items, B, cfg->last_activation); }
+                               (const uint16_t *)feat, mlp, src, out, sigma_out, depth_out, n_items, B, cfg->last_activation, omap); }
             return check_launch("mlp16_forward_kernel");
         }
     }
@@ -924,7 +942,7 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     const uint64_t waves_needed = kRays ? n_items : ((uint64_t)n_items + 31) / 32;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, 256u * 8u));
     { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, out, sigma_out,
-                       depth_out, n_items, B, cfg->last_activation); }
+                       depth_out, n_items, B, cfg->last_activation, omap); }
     return check_launch("mlp_forward_kernel");
 }
 
@@ -1126,6 +1144,15 @@ static int field_forward_impl(const float *pts, const void *emb, const int32_t *
     return run_mlp_forward<P, C, false>(w.feat, mlp, none, sigma, B, B, cfg, s);
 }
 
+template <typename P, uint32_t C>
+static int field_forward_grid_impl(const SrcGrid &src, const void *emb, const int32_t *offsets, const float *mlp, float *sigma, uint32_t B,
+                                   const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+    const Workspace w = carve(ws, cfg, B);
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    SrcRays none{};
+    return run_mlp_forward<P, C, false>(w.feat, mlp, none, sigma, B, B, cfg, s, nullptr, nullptr, OutMap{src.n[0], src.n[1], src.n[2]});
+}
+
 #define NAF_DISPATCH_PC(FN, ...)                                                                      \
     do {                                                                                              \
         if (cfg->mlp_precision == NAF_F32) {                                                          \
@@ -1273,4 +1300,29 @@ extern "C" int naf_field_forward(const float *pts, const void *embeddings, const
     if (int rc = check_points(B)) return rc;
     if (B == 0) return NAF_OK;
     NAF_DISPATCH_PC(field_forward_impl, pts, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);
+}
+
+extern "C" int naf_field_forward_grid(const double *start, const double *stop, const uint32_t *dims, const void *embeddings,
+                                      const int32_t *offsets, const float *mlp, float *sigma, const naf_render_cfg *cfg,
+                                      void *workspace, void *stream) {
+    if (int rc = check_cfg(cfg, "field_forward_grid")) return rc;
+    if (!start || !stop || !dims || !embeddings || !offsets || !mlp || !sigma || !workspace)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward_grid: null pointer");
+    SrcGrid src;
+    uint64_t total = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (dims[d] == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward_grid: empty axis");
+        // the reference raises for points outside [-bound, bound] (hashgrid.py:122-123); a grid is checked at its ends
+        if (!(std::fabs(start[d]) <= (double)cfg->bound) || !(std::fabs(stop[d]) <= (double)cfg->bound))
+            return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward_grid: grid exceeds [-bound, bound]");
+        src.start[d] = start[d];
+        src.stop[d] = stop[d];
+        src.step[d] = dims[d] > 1 ? (stop[d] - start[d]) / (double)(dims[d] - 1) : 0.0;      // numpy.linspace's step
+        src.n[d] = dims[d];
+        total *= dims[d];
+    }
+    src.bound = cfg->bound;
+    if (int rc = check_points(total)) return rc;
+    const uint32_t B = (uint32_t)total;
+    NAF_DISPATCH_PC(field_forward_grid_impl, src, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);
 }

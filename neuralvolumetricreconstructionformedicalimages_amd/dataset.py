@@ -96,6 +96,12 @@ class TIGREDataset(Dataset):
             self._voxels = torch.tensor(get_voxels(self.geo), dtype=torch.float32, device=self.device)
         return self._voxels
 
+    @property
+    def voxel_axes(self):
+        """(starts, stops, dims) of the voxel grid: axis k is numpy.linspace(starts[k], stops[k], dims[k]) (tigre.py:388-400)."""
+        s = self.geo.sVoxel / 2 - self.geo.dVoxel / 2
+        return [-float(v) for v in s], [float(v) for v in s], [int(v) for v in self.geo.nVoxel]
+
     def __len__(self):
         return self.n_samples
 

@@ -165,6 +165,28 @@ def render_samples(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_preci
 
 
 @torch.no_grad()
+def field_query_grid(net, starts, stops, dims, mlp_precision=None):
+    """sigma on the regular grid whose axis k is numpy.linspace(starts[k], stops[k], dims[k]) -> [d0, d1, d2]
+    (`naf_field_forward_grid`): the volume query of train.py:246-250 without materialising the [n^3, 3] point list, bit-identical
+    to `field_query` on it and faster (the kernel walks the grid along x)."""
+    enc = net.encoder
+    device = enc.embeddings.device
+    dims = [int(v) for v in dims]
+    B = dims[0] * dims[1] * dims[2]
+    if max(abs(float(v)) for v in list(starts) + list(stops)) > net.bound:
+        raise ValueError(f"HashGrid encoder: inputs range [{min(starts)}, {max(stops)}] not in [{-net.bound}, {net.bound}]!")
+    cfg = render_cfg(net, 2, False, mlp_precision)
+    ws = workspace(cfg, B, device)
+    sigma = torch.empty(dims, device=device, dtype=torch.float32)
+    a, b, d = (ctypes.c_double * 3)(*[float(v) for v in starts]), (ctypes.c_double * 3)(*[float(v) for v in stops]), (ctypes.c_uint32 * 3)(*dims)
+    _abi.check(_abi.lib().naf_field_forward_grid(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), _abi.ptr(enc.embeddings.detach().contiguous()),
+                                                 _abi.ptr(_offsets(enc, device)), _abi.ptr(net.packed_mlp().contiguous()), _abi.ptr(sigma),
+                                                 ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "field_forward_grid")
+    _bump(device)
+    return sigma
+
+
+@torch.no_grad()
 def field_query(net, pts, mlp_precision=None):
     """sigma(pts) for a point cloud [..., 3] in [-bound, bound] -> [..., 1] (volume query, train.py:246-250)."""
     enc = net.encoder

@@ -47,7 +47,10 @@ def timed(fn):
 
 with torch.no_grad():
     t_vol = timed(lambda: fused.field_query(net, voxels))
+    sv = geo.sVoxel / 2 - geo.dVoxel / 2
+    t_grid = timed(lambda: fused.field_query_grid(net, [-float(v) for v in sv], [float(v) for v in sv], [256, 256, 256]))
     t_proj = timed(lambda: fused.fused_render(rays, net, 192, False))
 print(json.dumps({"precision": args.precision,
                   "volume_query_256^3": {"points": voxels.numel() // 3, "ms": round(t_vol * 1e3, 3), "points_per_s": voxels.numel() / 3 / t_vol},
+                  "volume_query_256^3_generated_grid": {"ms": round(t_grid * 1e3, 3), "points_per_s": voxels.numel() / 3 / t_grid},
                   "projection_512x512_S192": {"rays": rays.shape[0], "ms": round(t_proj * 1e3, 3), "rays_per_s": rays.shape[0] / t_proj}}))
