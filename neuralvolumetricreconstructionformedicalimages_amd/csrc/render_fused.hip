@@ -784,15 +784,12 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
-    // A tile's block holds four pair records per point plus the second halves of unpaired pairs (1.6 % on average, but ALL
-    // pairs of a ray that keeps an x cell with index 63 mod 64 for its whole length): as many slots as let two pass-1
-    // workgroups share a CU's 160 KB of LDS (1.6x for 12-byte records), at least 1.25x.  A tile that still fills its block
-    // spills the excess to atomics (correct, counted).  A multiple of 32 records: blocks start on 128-byte lines.
-    {
-        const size_t lds_half = ((size_t)80 << 10) - (2u * ((size_t)1 << log2_nb) + 4u) * 4u;
-        const uint32_t fit = (uint32_t)(lds_half / rec) & ~31u, least = ((tile * 5u) + 31u) & ~31u;
-        plan->slots = std::min<uint32_t>(65504u, std::max(least, std::min(fit, tile * 8u)));
-    }
+    // A tile's block holds four pair records per point plus the second halves of unpaired pairs: 1.6 % on average, but ALL
+    // pairs of a ray that keeps an x cell with index 63 mod 64 for its whole length (seen at T = 2^22, where 1.25x was not
+    // always enough).  1.375x; a tile that still fills its block spills the excess to atomics (correct, counted).  More
+    // would fit the LDS next to a second workgroup, but the larger allocation measured 2-3 % slower.  A multiple of 32
+    // records: blocks start on 128-byte lines.
+    plan->slots = std::min<uint32_t>(65504u, ((tile * 11u / 2u) + 31u) & ~31u);
     // pass 2 reads a bucket's run of a tile with W lanes: W = the power of two >= 1.25 x the mean run length, at most a wave
     const uint32_t mean_run = std::max<uint32_t>(1u, (tile * 4u) >> log2_nb);
     plan->log2_w = 3u;
