@@ -33,16 +33,23 @@ timeout -k 10 300 python bench.py --force-dp --steps 10 --warmup 3 --cpu-seconds
 echo modes done
 timeout -k 10 200 python tools/eval_bench.py > $OUT/eval.jsonl 2> $OUT/eval.err
 timeout -k 10 200 python tools/eval_bench.py --precision fp32 >> $OUT/eval.jsonl 2>> $OUT/eval.err
-timeout -k 10 300 python tools/train_throughput.py > $OUT/train_py.json 2> $OUT/train_py.err
+timeout -k 10 300 python tools/train_throughput.py 2> $OUT/train_py.err | grep "^{" | tail -n 1 > $OUT/train_py.json
 for a in "--log2T 22 --samples 320 --table fp16 --rays 32768" "--log2T 21 --samples 192 --table bf16 --rays 32768" "--log2T 20 --samples 192 --table bf16 --rays 65536" "--log2T 19 --samples 576 --table bf16 --rays 16384" "--log2T 19 --samples 192 --table bf16 --rays 65536"; do
   timeout -k 10 100 python tools/step_bench.py $a 2>> $OUT/shapes.err | tail -n 1 >> $OUT/shapes.jsonl
 done
 echo eval + shapes done
+# T = 2^22 (foot_50 shapes, the table is larger than every cache level below the Infinity Cache): HBM bytes fetched by the
+# encoder of the FUSED forward, quoted against the north star's 60 % bar in DESIGN.md section 4.1
+for t in fp16 fp32; do
+  timeout -k 10 200 python tools/step_bench.py --log2T 22 --samples 320 --table $t --rays 32768 2>> $OUT/shapes.err | tail -n 1 > $OUT/t22_${t}_plain.json
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/t22_$t -o t22 -- python3 tools/step_bench.py --log2T 22 --samples 320 --table $t --rays 32768 --steps 3 > $OUT/t22_${t}_pmc.json 2> $OUT/t22_$t.err
+done
+echo T22 fetch done
 timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --out $OUT/psnr_16384_bf16.json > $OUT/psnr_a.log 2>&1
 timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --precision fp32 --out $OUT/psnr_16384_fp32.json > $OUT/psnr_b.log 2>&1
 timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-every 5000 --out $OUT/psnr_1024_bf16.json > $OUT/psnr_c.log 2>&1
 echo all done
 # summarise on the box and keep only the summaries (the kernel traces alone exceed what gpurun copies back)
 NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round2}
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/sqa $OUT/sqb
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/sqa $OUT/sqb $OUT/t22_fp16 $OUT/t22_fp32
 ls gpurun_out/profiles_staged

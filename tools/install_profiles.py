@@ -64,6 +64,29 @@ json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 print("profiles/pmc_traffic.json", {k: round(v / 1e9, 2) for k, v in traffic["bf16"].items()})
 
 
+# ---- T = 2^22: HBM bytes fetched by the fused forward's encoder ----------------------------------------------------------
+t22 = {"_comment": "foot_50 shapes (L=16, T=2^22, S=320, 32768 rays = 10.49 M points per launch): encode_kernel of the fused training step. "
+                   "FETCH_SIZE from `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/step_bench.py --log2T 22 --samples 320 --table <t> --rays 32768 --steps 3` "
+                   "(value * 1024; random 4/8-byte gathers fetch 64-byte sectors, so no x2 correction is applied: the doubled figure is listed "
+                   "separately), kernel time of the same launches WITHOUT counters from the plain run"}
+for t in ("fp16", "fp32"):
+    csv_path = os.path.join(SRC, f"t22_{t}", "t22_counter_collection.csv")
+    plain = os.path.join(SRC, f"t22_{t}_plain.json")
+    if not (os.path.exists(csv_path) and os.path.exists(plain)):
+        continue
+    import csv as _csv
+    vals = [float(r["Counter_Value"]) * 1024 for r in _csv.DictReader(open(csv_path))
+            if "encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    run = json.loads(open(plain).read().strip().splitlines()[-1])
+    ms = run["kernels_ms_per_step"]["encode_kernel"]
+    fetched = sum(vals) / max(len(vals), 1)
+    t22[t] = {"table_MB": run["table_MB"], "encode_kernel_ms": ms, "dispatches_counted": len(vals), "fetch_bytes_per_launch": fetched,
+              "hbm_read_TBps": fetched / (ms * 1e-3) / 1e12, "fraction_of_8TBps": fetched / (ms * 1e-3) / 8e12,
+              "fetch_bytes_per_launch_if_doubled": 2 * fetched, "step_ms": run["ms_per_step"], "step_kernels_ms": run["kernels_ms_per_step"]}
+if len(t22) > 1:
+    json.dump(t22, open(os.path.join(DST, f"{TAG}_hash_forward_T22_fetch.json"), "w"), indent=1)
+    print(f"profiles/{TAG}_hash_forward_T22_fetch.json", {k: (round(v["hbm_read_TBps"], 2), v["encode_kernel_ms"]) for k, v in t22.items() if k != "_comment"})
+
 # ---- SQ instruction mix and MFMA utilisation -------------------------------------------------------------------------
 import collections  # noqa: E402
 import csv  # noqa: E402

@@ -56,7 +56,7 @@ class BasicTrainer(Trainer):
             else:
                 calc_mse_loss(loss, target, pred)
         for ls in loss.keys():
-            self.writer.add_scalar(f"train/{ls}", float(loss[ls]), global_step)
+            self.writer.add_scalar(f"train/{ls}", float(loss[ls].detach()) if torch.is_tensor(loss[ls]) else float(loss[ls]), global_step)
         return loss["loss"]
 
     def eval_step(self, global_step, idx_epoch):
