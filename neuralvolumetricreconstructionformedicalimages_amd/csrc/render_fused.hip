@@ -772,6 +772,7 @@ static size_t record_bytes(const naf_render_cfg *cfg) {
 // pass-1 tile shape, the host mirror of BinShape<Rec>
 static uint32_t bin_threads(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 12 ? 512u : 256u; }
 static uint32_t bin_points_per_thread(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 20 ? 2u : 1u; }
+constexpr uint32_t kBigTileLog2Nb = 7u;                  // buckets per level from which pass 1 uses its 1024-thread shape
 
 static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan *plan) {
     if (cfg->scatter_mode == NAF_SCATTER_ATOMIC || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
@@ -780,7 +781,11 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
     const size_t rec = record_bytes(cfg);
-    const uint32_t tile = bin_threads(cfg) * bin_points_per_thread(cfg);
+    // Tables of 2^20 rows per level and more need 128 .. 512 buckets (the reducer's rows must fit the LDS), which cuts a
+    // 1024-point tile into runs of 8 .. 32 records -- short, ragged reads in pass 2.  With 12-byte records a 2048-point
+    // tile (ONE workgroup of 1024 threads per CU instead of two of 512: the same 16 waves) still fits the LDS.
+    const bool big = rec <= 12 && log2_nb >= kBigTileLog2Nb;
+    const uint32_t tile = bin_threads(cfg) * bin_points_per_thread(cfg) * (big ? 2u : 1u);
     plan->tile_points = tile;
     plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
     plan->log2_nb = log2_nb;
@@ -983,10 +988,16 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     // four when tiles are scarce (1 024-ray steps: 0.093 -> 0.071 ms)
     constexpr uint32_t kLvMany = 16u, kLvFew = 4u;
     const BinPlan &plan = w.plan;
-    if (plan.tile_points != NT * PTS) return fail(NAF_ERR_LAUNCH, "binned scatter: plan / kernel tile mismatch");
-    const bool many = plan.n_tiles >= 1536u;
+    constexpr bool kHasBig = sizeof(Rec) <= 12;                 // the 1024-thread shape of pass 1 (make_bin_plan)
+    const bool big = kHasBig && plan.tile_points == 2u * NT * PTS;
+    if (!big && plan.tile_points != NT * PTS) return fail(NAF_ERR_LAUNCH, "binned scatter: plan / kernel tile mismatch");
+    const uint32_t threads = big ? 2u * NT : NT;
+    const bool many = plan.n_tiles >= (big ? 768u : 1536u);
     const uint32_t LV = many ? kLvMany : kLvFew;
     auto bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, NT, PTS, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, NT, PTS, kLvFew>;
+    if constexpr (kHasBig) {
+        if (big) bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvFew>;
+    }
     auto red = scatter_reduce_kernel<C, Rec>;
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;
@@ -999,7 +1010,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     // pass 1 over the levels [l0, l0 + nl): their records fill the region buffer from level slot 0
     auto launch_bin = [&](uint32_t l0, uint32_t nl) -> int {
         ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
-        hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(NT), bin_lds, s, src, (const typename FT::store_t *)dfeat,
+        hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const typename FT::store_t *)dfeat,
                            offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan);
         return check_launch("scatter_bin_kernel");
     };
@@ -1199,11 +1210,18 @@ static int check_points(uint64_t n_points) {
     if (n_points >= (1ull << 31)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: more than 2^31 points per call; split the batch");
     return NAF_OK;
 }
+// NAF_CFG_EXPLICIT_DEPTHS makes t_rand the [n_rays, n_samples] depths themselves: it cannot be absent then
+static int check_depths(const naf_render_cfg *cfg, const float *t_rand) {
+    if ((cfg->flags & NAF_CFG_EXPLICIT_DEPTHS) != 0u && t_rand == nullptr)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render: NAF_CFG_EXPLICIT_DEPTHS needs the depths in t_rand");
+    return NAF_OK;
+}
 
 extern "C" int naf_render_forward(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
                                   const float *mlp, float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
                                   void *stream) {
     if (int rc = check_cfg(cfg, "render_forward")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
     if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
@@ -1215,6 +1233,7 @@ extern "C" int naf_render_forward_samples(const float *rays, const float *t_rand
                                           const float *mlp, float *acc, float *sigma, float *optical_depth, uint32_t n_rays,
                                           const naf_render_cfg *cfg, void *workspace, void *stream) {
     if (int rc = check_cfg(cfg, "render_forward_samples")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
     if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
@@ -1227,6 +1246,7 @@ extern "C" int naf_render_backward(const float *rays, const float *t_rand, const
                                    const int32_t *offsets, const float *mlp, float *grad_embeddings, float *grad_mlp,
                                    uint32_t n_rays, const naf_render_cfg *cfg, void *workspace, int features_valid, void *stream) {
     if (int rc = check_cfg(cfg, "render_backward")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
     if (!rays || !grad_acc || !embeddings || !offsets || !mlp || !grad_embeddings || !grad_mlp || !workspace)
         return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: n_samples must be >= 2");
@@ -1255,6 +1275,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
     if (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace)
         return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: n_samples must be >= 2");
@@ -1316,10 +1337,10 @@ extern "C" int naf_field_forward_grid(const double *start, const double *stop, c
         src.stop[d] = stop[d];
         src.step[d] = dims[d] > 1 ? (stop[d] - start[d]) / (double)(dims[d] - 1) : 0.0;      // numpy.linspace's step
         src.n[d] = dims[d];
-        total *= dims[d];
+        total *= dims[d];                                    // < 2^31 * 2^32 per step: checked before it can wrap
+        if (int rc = check_points(total)) return rc;
     }
     src.bound = cfg->bound;
-    if (int rc = check_points(total)) return rc;
     const uint32_t B = (uint32_t)total;
     NAF_DISPATCH_PC(field_forward_grid_impl, src, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);
 }

@@ -338,9 +338,15 @@ __device__ __forceinline__ void make_ray(const float *__restrict__ poses, uint64
 
 __global__ void __launch_bounds__(256)
 generate_rays_kernel(const float *__restrict__ poses, const int64_t *__restrict__ pixels, int64_t first_pixel,
-                     float *__restrict__ rays, uint64_t n, RayGeo g) {
+                     float *__restrict__ rays, uint64_t n, RayGeo g, uint64_t n_pixels) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t flat = pixels ? (uint64_t)pixels[i] : (uint64_t)first_pixel + i;
+        if (flat >= n_pixels) {                                 // list entry outside the scan (negative ones included): a NaN ray, no pose read
+            const float nan = __builtin_nanf("");
+            reinterpret_cast<float4 *>(rays + i * 8)[0] = make_float4(nan, nan, nan, nan);
+            reinterpret_cast<float4 *>(rays + i * 8)[1] = make_float4(nan, nan, g.near, g.far);
+            continue;
+        }
         make_ray(poses, flat, g, reinterpret_cast<float4 *>(rays + i * 8));
     }
 }
@@ -378,7 +384,7 @@ __device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_t n, uint
 __global__ void __launch_bounds__(256)
 draw_scan_rays_kernel(ScanDraw draw, const float *__restrict__ poses, const float *__restrict__ projections,
                       int64_t *__restrict__ pixels, float *__restrict__ target, float *__restrict__ rays, uint32_t first,
-                      uint32_t count, RayGeo g, uint64_t seed) {
+                      uint32_t count, RayGeo g, uint64_t seed, uint64_t n_pixels) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         const uint32_t i = first + t;                           // global draw index: segment-major
         const uint32_t seg = i / draw.per_segment, k = i - seg * draw.per_segment;
@@ -388,6 +394,13 @@ draw_scan_rays_kernel(ScanDraw draw, const float *__restrict__ poses, const floa
         const uint32_t idx = feistel_permute(k, n, half_bits, seed + 0x632be59bd9b4e019ull * (seg + 1u));
         const int64_t flat = draw.valid[seg][idx];
         if (pixels) pixels[t] = flat;
+        if ((uint64_t)flat >= n_pixels) {                       // a list entry outside the scan (the reference's fancy index would raise):
+            const float nan = __builtin_nanf("");               // nothing is read through it, the ray and its value are NaN
+            if (target) target[t] = nan;
+            reinterpret_cast<float4 *>(rays + (size_t)t * 8)[0] = make_float4(nan, nan, nan, nan);
+            reinterpret_cast<float4 *>(rays + (size_t)t * 8)[1] = make_float4(nan, nan, g.near, g.far);
+            continue;
+        }
         if (target) target[t] = projections[flat];
         make_ray(poses, (uint64_t)flat, g, reinterpret_cast<float4 *>(rays + (size_t)t * 8));
     }
@@ -406,6 +419,7 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
     if (det_w == 0 || det_h == 0 || n_projections == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: empty detector");
     if (((uintptr_t)rays) & 15u) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: rays must be 16-byte aligned");
     const uint64_t total = (uint64_t)draw->n_segments * draw->rays_per_segment;
+    if (total > 0xffffffffull) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: more than 2^32 - 1 draws per call");
     if ((uint64_t)first_draw + n_draws > total) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: draw range outside n_segments * rays_per_segment");
     ScanDraw d;
     d.n_segments = draw->n_segments;
@@ -423,7 +437,7 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
     RayGeo g{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
     { ProfScope prof_("draw_scan_rays_kernel", (hipStream_t)stream);
       hipLaunchKernelGGL(draw_scan_rays_kernel, dim3(grid_for(n_draws, 256)), dim3(256), 0, (hipStream_t)stream, d, poses, projections,
-                         pixels, target, rays, first_draw, n_draws, g, seed); }
+                         pixels, target, rays, first_draw, n_draws, g, seed, (uint64_t)n_projections * det_w * det_h); }
     return check_launch("draw_scan_rays_kernel");
 }
 
@@ -438,6 +452,6 @@ extern "C" int naf_generate_rays(const float *poses, const int64_t *pixels, int6
     if (n == 0) return NAF_OK;
     RayGeo g{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
     { ProfScope prof_("generate_rays_kernel", (hipStream_t)stream); hipLaunchKernelGGL(generate_rays_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, poses, pixels,
-                       first_pixel, rays, n, g); }
+                       first_pixel, rays, n, g, (uint64_t)n_projections * det_w * det_h); }
     return check_launch("generate_rays_kernel");
 }

@@ -156,7 +156,7 @@ __device__ __forceinline__ size_t block_index(const BinPlan &plan, uint32_t ly, 
 // (B) wave 0 turns the histogram into exclusive offsets and publishes (start, length) of every run, (C) every thread takes
 // its slots (ds_add_rtn_u32 on the cursors) and writes its records, (D) the dense, bucket-sorted block leaves for HBM.
 template <typename FT, uint32_t C, typename Src, typename Rec, uint32_t NT, uint32_t PTS, uint32_t LV>
-__global__ void __launch_bounds__(NT, NT == 512u ? 4 : 2)       // 512 threads: two workgroups (16 waves) per CU -> <= 128 VGPRs
+__global__ void __launch_bounds__(NT, NT >= 512u ? 4 : 2)       // 512 threads: two workgroups (16 waves) per CU -> <= 128 VGPRs; 1024: one
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ blocks, uint32_t *__restrict__ runs,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,

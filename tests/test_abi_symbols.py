@@ -65,6 +65,16 @@ def test_argument_validation_needs_no_gpu():
     assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None) == -1
     with pytest.raises(RuntimeError, match="scatter_mode"):
         _abi.check(lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None), "render_forward")
+    # explicit depths (the fine pass) travel in t_rand: it cannot be absent then
+    cfg.flags = _abi.CFG_EXPLICIT_DEPTHS
+    assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(cfg), one, None) == -1
+    assert b"EXPLICIT_DEPTHS" in lib.naf_last_error()
+    # a voxel grid of more than 2^31 points is refused before its size can wrap
+    cfg.flags = 0
+    dims = (ctypes.c_uint32 * 3)(0xffffffff, 0xffffffff, 0xffffffff)
+    ends = (ctypes.c_double * 3)(-0.1, -0.1, -0.1), (ctypes.c_double * 3)(0.1, 0.1, 0.1)
+    assert lib.naf_field_forward_grid(ends[0], ends[1], dims, one, one, one, one, ctypes.byref(cfg), one, None) == -1
+    assert b"2^31 points" in lib.naf_last_error()
 
 
 def test_product_has_no_cpu_fallback():

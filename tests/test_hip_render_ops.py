@@ -160,3 +160,10 @@ def test_draw_scan_rays_distinct_valid_uniform_and_shardable():
     assert float(counts.sum()) == trials * m and float((c - expect).abs().max()) < 6 * expect ** 0.5 + 3
     with pytest.raises(ValueError, match="larger sample than population"):
         gen.draw(valid[:1], n1 + 1, seed=1)
+    # a list entry outside the scan (the reference's fancy index would raise): nothing is read through it, its ray and value are NaN
+    bad = valid[0].clone()
+    bad[5] = 4 * hw + 123
+    pb, tb2, rb2 = gen.draw([bad], n1, seed=3, projections=projs)
+    hit = pb == 4 * hw + 123
+    assert int(hit.sum()) == 1 and bool(torch.isnan(tb2[hit]).all()) and bool(torch.isnan(rb2[hit][:, :6]).all())
+    assert torch.equal(tb2[~hit], projs[pb[~hit]]) and torch.equal(rb2[~hit], gen.rays_for_pixels(pb[~hit]))
