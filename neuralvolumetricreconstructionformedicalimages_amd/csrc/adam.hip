@@ -69,7 +69,7 @@ using namespace naf;
 extern "C" int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype,
                              uint64_t n, float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale,
                              int zero_grad, void *stream) {
-    if (!param || !exp_avg || !exp_avg_sq || !grad) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: null pointer");
+    if (n != 0 && (!param || !exp_avg || !exp_avg_sq || !grad)) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: null pointer");
     if (step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: step is 1-based");
     if (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad) & 15u)
         return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: buffers must be 16-byte aligned");

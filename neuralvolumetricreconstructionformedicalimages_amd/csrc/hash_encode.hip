@@ -77,7 +77,7 @@ static int check_dims(uint32_t D, uint32_t C) {
 extern "C" int naf_hash_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets,
                                        void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H,
                                        int calc_grad_inputs, void *dy_dx, int dtype, int out_layout, void *stream) {
-    if (!inputs || !embeddings || !offsets || !outputs) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: null pointer");
+    if (B != 0 && (!inputs || !embeddings || !offsets || !outputs)) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: null pointer");
     if (calc_grad_inputs < NAF_GRAD_INPUTS_NONE || calc_grad_inputs > NAF_GRAD_INPUTS_REFERENCE)
         return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: calc_grad_inputs must be NAF_GRAD_INPUTS_NONE, _EXACT or _REFERENCE");
     if (calc_grad_inputs && !dy_dx) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_forward: calc_grad_inputs without dy_dx");
@@ -101,7 +101,7 @@ extern "C" int naf_hash_encode_backward(const void *grad, const float *inputs, c
                                         uint32_t C, uint32_t L, uint32_t H, int calc_grad_inputs, const void *dy_dx,
                                         float *grad_inputs, int dtype, int grad_layout, void *stream) {
     (void)embeddings;   // kept for signature parity with hashencoder.h:14; the scatter does not read the table
-    if (!grad || !inputs || !offsets || !grad_embeddings) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_backward: null pointer");
+    if (B != 0 && (!grad || !inputs || !offsets || !grad_embeddings)) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_backward: null pointer");
     if (calc_grad_inputs && (!dy_dx || !grad_inputs)) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_backward: calc_grad_inputs without dy_dx/grad_inputs");
     if (L == 0 || L > 65535u) return fail(NAF_ERR_INVALID_ARGUMENT, "hash_encode_backward: L must be in [1, 65535]");
     if (int rc = check_dims(D, C)) return rc;

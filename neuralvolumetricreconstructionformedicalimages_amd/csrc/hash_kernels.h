@@ -92,7 +92,7 @@ struct SrcGrid {
 // (c) sample s of ray r (b = r*S + s): stratified depth, point on ray, clamp, normalise
 //     (render.py:87-105 + hashgrid.py:125) -- nothing [B,3]-sized ever touches HBM.
 struct SrcRays {
-    static constexpr bool kInRange = true;       // get() clamps to +-(bound - 1e-6) like render.py:104-105 (NaN -> the clamp value)
+    static constexpr bool kInRange = true;       // get() clamps to +-(bound - 1e-6) like render.py:104-105; a NaN stays NaN and lands in cell 0 (locate)
     const float *__restrict__ rays;    // [n_rays, 8]
     const float *__restrict__ t_rand;  // [n_rays, S] or nullptr
     uint32_t S;
@@ -142,7 +142,8 @@ struct SrcRays {
 #pragma unroll
         for (uint32_t d = 0; d < 3; ++d) {
             float p = o[d] + dir[d] * z;
-            p = fminf(fmaxf(p, -lim), lim);
+            p = p < -lim ? -lim : p;                   // torch.clamp (render.py:104-105): a NaN position stays NaN and poisons its
+            p = p > lim ? lim : p;                     // ray like the reference; fminf / fmaxf would turn it into the clamp value
             out[d] = div_exact(p + bound, denom, rden);
         }
     }

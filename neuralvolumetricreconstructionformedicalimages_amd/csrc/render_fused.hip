@@ -1222,7 +1222,7 @@ extern "C" int naf_render_forward(const float *rays, const float *t_rand, const 
                                   void *stream) {
     if (int rc = check_cfg(cfg, "render_forward")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
-    if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: null pointer");
+    if (n_rays != 0 && (!rays || !embeddings || !offsets || !mlp || !acc || !workspace)) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
     if (n_rays == 0) return NAF_OK;
@@ -1234,7 +1234,7 @@ extern "C" int naf_render_forward_samples(const float *rays, const float *t_rand
                                           const naf_render_cfg *cfg, void *workspace, void *stream) {
     if (int rc = check_cfg(cfg, "render_forward_samples")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
-    if (!rays || !embeddings || !offsets || !mlp || !acc || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: null pointer");
+    if (n_rays != 0 && (!rays || !embeddings || !offsets || !mlp || !acc || !workspace)) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_forward_samples: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
     if (n_rays == 0) return NAF_OK;
@@ -1247,7 +1247,7 @@ extern "C" int naf_render_backward(const float *rays, const float *t_rand, const
                                    uint32_t n_rays, const naf_render_cfg *cfg, void *workspace, int features_valid, void *stream) {
     if (int rc = check_cfg(cfg, "render_backward")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
-    if (!rays || !grad_acc || !embeddings || !offsets || !mlp || !grad_embeddings || !grad_mlp || !workspace)
+    if (n_rays != 0 && (!rays || !grad_acc || !embeddings || !offsets || !mlp || !grad_embeddings || !grad_mlp || !workspace))
         return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_backward: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
@@ -1276,7 +1276,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
-    if (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace)
+    if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
         return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
@@ -1314,7 +1314,7 @@ extern "C" int naf_render_train_bucketed(const float *rays, const float *t_rand,
 extern "C" int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,
                                  float *sigma, uint32_t B, const naf_render_cfg *cfg, void *workspace, void *stream) {
     if (int rc = check_cfg(cfg, "field_forward")) return rc;
-    if (!pts || !embeddings || !offsets || !mlp || !sigma || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward: null pointer");
+    if (B != 0 && (!pts || !embeddings || !offsets || !mlp || !sigma || !workspace)) return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward: null pointer");
     if (int rc = check_points(B)) return rc;
     if (B == 0) return NAF_OK;
     NAF_DISPATCH_PC(field_forward_impl, pts, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);

@@ -27,7 +27,8 @@ sample_rays_kernel(const float *__restrict__ rays, const float *__restrict__ t_r
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float p = ray[d] + ray[3 + d] * z;          // mul then add, as torch evaluates it
-            p = fminf(fmaxf(p, -lim), lim);
+            p = p < -lim ? -lim : p;                    // torch.clamp: a NaN position stays NaN (fminf / fmaxf would drop it)
+            p = p > lim ? lim : p;
             pts[i * 3 + d] = p;
         }
     }
@@ -231,7 +232,7 @@ using namespace naf;
 extern "C" int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float *pts, uint32_t n_rays,
                                uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,
                                void *stream) {
-    if (!rays || !z_vals || !pts) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: null pointer");
+    if (n_rays != 0 && (!rays || !z_vals || !pts)) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: null pointer");
     if (n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: n_samples must be >= 2");
     if (n_rays == 0) return NAF_OK;
     const uint64_t total = (uint64_t)n_rays * n_samples;
@@ -242,7 +243,7 @@ extern "C" int naf_sample_rays(const float *rays, const float *t_rand, float *z_
 
 extern "C" int naf_integrate_forward(const float *sigma, const float *z_vals, const float *rays, float *acc,
                                      uint32_t n_rays, uint32_t n_samples, void *stream) {
-    if (!sigma || !z_vals || !rays || !acc) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_forward: null pointer");
+    if (n_rays != 0 && (!sigma || !z_vals || !rays || !acc)) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_forward: null pointer");
     if (n_rays == 0) return NAF_OK;
     { ProfScope prof_("integrate_forward_kernel", (hipStream_t)stream); hipLaunchKernelGGL(integrate_forward_kernel, dim3(grid_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
                        z_vals, rays, acc, n_rays, n_samples); }
@@ -251,7 +252,7 @@ extern "C" int naf_integrate_forward(const float *sigma, const float *z_vals, co
 
 extern "C" int naf_integrate_backward(const float *grad_acc, const float *z_vals, const float *rays, float *grad_sigma,
                                       uint32_t n_rays, uint32_t n_samples, void *stream) {
-    if (!grad_acc || !z_vals || !rays || !grad_sigma) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_backward: null pointer");
+    if (n_rays != 0 && (!grad_acc || !z_vals || !rays || !grad_sigma)) return fail(NAF_ERR_INVALID_ARGUMENT, "integrate_backward: null pointer");
     if (n_rays == 0) return NAF_OK;
     const uint64_t total = (uint64_t)n_rays * n_samples;
     { ProfScope prof_("integrate_backward_kernel", (hipStream_t)stream); hipLaunchKernelGGL(integrate_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -262,7 +263,7 @@ extern "C" int naf_integrate_backward(const float *grad_acc, const float *z_vals
 extern "C" int naf_fine_depths(const float *rays, const float *t_rand, const float *sigma, const float *u, float *z_out,
                                float *weights_out, uint32_t n_rays, uint32_t n_samples, uint32_t n_fine, int perturb, int det,
                                uint64_t seed, uint32_t ray_index_base, void *scratch, void *stream) {
-    if (!rays || !sigma || !z_out || !scratch) return fail(NAF_ERR_INVALID_ARGUMENT, "fine_depths: null pointer");
+    if (n_rays != 0 && (!rays || !sigma || !z_out || !scratch)) return fail(NAF_ERR_INVALID_ARGUMENT, "fine_depths: null pointer");
     if (n_samples < 3 || n_fine == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "fine_depths: needs n_samples >= 3 and n_fine >= 1");
     if (n_samples > 1024u || n_samples + n_fine > 2048u)
         return fail(NAF_ERR_UNSUPPORTED, "fine_depths: at most 1024 coarse and 2048 merged depths per ray (LDS-resident sort)");
@@ -287,7 +288,7 @@ extern "C" int naf_fine_depths(const float *rays, const float *t_rand, const flo
 }
 
 extern "C" int naf_normalize_inputs(const float *x, uint64_t n, float size, float *out01, int32_t *flag, void *stream) {
-    if (!x || !flag) return fail(NAF_ERR_INVALID_ARGUMENT, "normalize_inputs: null pointer");
+    if (n != 0 && (!x || !flag)) return fail(NAF_ERR_INVALID_ARGUMENT, "normalize_inputs: null pointer");
     if (n == 0) return NAF_OK;
     { ProfScope prof_("normalize_inputs_kernel", (hipStream_t)stream); hipLaunchKernelGGL(normalize_inputs_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x, n,
                        size, out01, flag); }
@@ -412,12 +413,12 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
                                   float *target, float *rays, uint32_t first_draw, uint32_t n_draws, uint32_t n_projections,
                                   uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov, float DSD, float near,
                                   float far, int parallel, uint64_t seed, void *stream) {
-    if (!draw || !poses || !rays) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: null pointer");
-    if (target && !projections) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: target without projections");
+    if (!draw || (n_draws != 0 && (!poses || !rays))) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: null pointer");
+    if (n_draws != 0 && target && !projections) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: target without projections");
     if (draw->n_segments == 0 || draw->n_segments > NAF_MAX_DRAW_SEGMENTS || draw->rays_per_segment == 0)
         return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: n_segments must be in [1, 16] and rays_per_segment > 0");
     if (det_w == 0 || det_h == 0 || n_projections == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: empty detector");
-    if (((uintptr_t)rays) & 15u) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: rays must be 16-byte aligned");
+    if (n_draws != 0 && (((uintptr_t)rays) & 15u)) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: rays must be 16-byte aligned");
     const uint64_t total = (uint64_t)draw->n_segments * draw->rays_per_segment;
     if (total > 0xffffffffull) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: more than 2^32 - 1 draws per call");
     if ((uint64_t)first_draw + n_draws > total) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: draw range outside n_segments * rays_per_segment");
@@ -444,7 +445,7 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
 extern "C" int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,
                                  uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv, float ou,
                                  float ov, float DSD, float near, float far, int parallel, void *stream) {
-    if (!poses || !rays) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: null pointer");
+    if (n != 0 && (!poses || !rays)) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: null pointer");
     if (det_w == 0 || det_h == 0 || n_projections == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: empty detector");
     if (((uintptr_t)rays) & 15u) return fail(NAF_ERR_INVALID_ARGUMENT, "generate_rays: rays must be 16-byte aligned");
     if (!pixels && (first_pixel < 0 || (uint64_t)first_pixel + n > (uint64_t)n_projections * det_w * det_h))

@@ -100,6 +100,8 @@ struct BinPlan {
 
 // Pass-1 shape by record size (compile time): 12-byte records (two bf16 channels) get 512 threads x 2 points -- 1024-point
 // tiles, a mean of 64 pair records per bucket, so a reducer wave is full; larger records get smaller tiles (LDS staging).
+// With 128 buckets per level and more (tables of 2^20 rows and up) the host launches the 12-byte shape with 2 x kThreads:
+// one 1024-thread workgroup per CU on a 2048-point tile, which doubles the run length pass 2 reads (make_bin_plan).
 template <typename Rec> struct BinShape {
     static constexpr uint32_t kThreads = sizeof(Rec) <= 12 ? 512u : 256u;
     static constexpr uint32_t kPoints = sizeof(Rec) <= 20 ? 2u : 1u;

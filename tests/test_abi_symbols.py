@@ -65,6 +65,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None) == -1
     with pytest.raises(RuntimeError, match="scatter_mode"):
         _abi.check(lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(atomic), one, None), "render_forward")
+    # an empty batch is a no-op whose per-batch pointers are not examined (zero-length chunks, empty data-parallel shards)
+    assert lib.naf_render_forward(None, None, None, None, None, None, 0, ctypes.byref(cfg), None, None) == 0
+    assert lib.naf_hash_encode_forward(None, None, None, None, 0, 3, 2, 16, 16, 0, None, 0, 0, None) == 0
+    assert lib.naf_adam_step(None, None, None, None, None, 0, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, 0, None) == 0
     # explicit depths (the fine pass) travel in t_rand: it cannot be absent then
     cfg.flags = _abi.CFG_EXPLICIT_DEPTHS
     assert lib.naf_render_forward(one, None, one, one, one, one, 8, ctypes.byref(cfg), one, None) == -1

@@ -1,0 +1,121 @@
+"""Edge cases of the hot path on the GPU, through the same entry points as the parity tests: empty and one-element
+inputs, the smallest legal sample count, rays that miss the volume (every sample clamped, render.py:103-105), non-finite
+rays, batches that straddle the atomic / binned scatter switch.  The reference has no tests of its own; these are the cases
+its code paths define (np.random.choice / fancy indexing on empty lists, `torch.clamp`, zero-length chunks in
+render.py:52-60)."""
+import numpy as np
+import pytest
+import torch
+
+from _naf_helpers import crossing_rays, naf_pair, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused
+    return _abi, fused
+
+
+def test_empty_inputs_are_no_ops_everywhere():
+    """Zero rays / zero points: every entry point returns empty outputs, launches nothing and leaves gradients at zero."""
+    _abi, fused = _mods()
+    from neuralvolumetricreconstructionformedicalimages_amd import encoder, phantom
+    from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
+    net, _ = naf_pair(seed=3, oracle=False)
+    rays = crossing_rays(4).cuda()
+    acc = fused.fused_render(rays[:0], net, 32, True)
+    assert acc.shape == (0,)
+    net.zero_grad()
+    (acc.sum() + 0.0 * net.encoder.embeddings.sum()).backward()
+    assert float(net.encoder.embeddings.grad.abs().max()) == 0.0
+    with torch.no_grad():
+        assert fused.field_query(net, torch.zeros(0, 3, device="cuda")).shape[0] == 0
+        a, sg, tau = fused.render_samples(rays[:0], net, 32, False)
+        assert a.shape == (0,) and sg.shape == (0, 32) and tau.shape == (0, 32)
+    enc = encoder.HashEncoder(3, 4, 2, 4, 8).cuda()
+    out = enc(torch.zeros(0, 3, device="cuda"), 0.3)
+    assert out.shape == (0, 8)
+    gen = RayGenerator(ConeGeometry(phantom.scan_geometry(16, "cone")), np.linspace(0, np.pi, 3)[:-1], torch.device("cuda"))
+    assert gen.rays_for_pixels(torch.zeros(0, dtype=torch.int64, device="cuda")).shape == (0, 8)
+
+
+@pytest.mark.parametrize("mode", [1, 2])            # atomic / binned scatter
+def test_one_ray_two_samples_vs_oracle(mode):
+    """The smallest legal call: one ray, S = 2 (render.py:88-100 needs two samples for the mid-points)."""
+    from oracle import render_ref as R
+    _abi, fused = _mods()
+    net, ref = naf_pair(seed=5)
+    rays = crossing_rays(1, seed=9)
+    t_rand = torch.tensor([[0.25, 0.75]])
+    acc_ref = R.render(rays, ref, None, 2, 0, True, 1 << 20, 0.0, t_rand=t_rand)["acc"]
+    (acc_ref ** 2).sum().backward()
+    with fused.scatter_mode(mode):
+        acc = fused.fused_render(rays.cuda(), net, 2, True, t_rand=t_rand.cuda())
+        (acc ** 2).sum().backward()
+    assert rel_l2(acc.detach().cpu().numpy(), acc_ref.detach().numpy()) < 1e-5
+    assert rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ref.encoder.embeddings.grad.numpy()) < 2e-4
+
+
+def test_rays_that_miss_the_volume_are_clamped_like_the_reference():
+    """All samples outside the +-bound cube: the reference clamps them to the faces (render.py:103-105) and still evaluates the
+    network there -- the result is finite, equals the oracle, and the table gradient lands on boundary cells only."""
+    from oracle import render_ref as R
+    _abi, fused = _mods()
+    net, ref = naf_pair(seed=6)
+    n, S = 12, 24
+    o = torch.tensor([[2.0, 2.0, 2.0]]).repeat(n, 1)
+    d = torch.nn.functional.normalize(torch.rand(n, 3, generator=torch.Generator().manual_seed(2)) + 0.2, dim=-1)   # pointing away
+    rays = torch.cat([o, d, torch.full((n, 1), 0.1), torch.full((n, 1), 3.0)], -1)
+    acc_ref = R.render(rays, ref, None, S, 0, False, 1 << 20, 0.0)["acc"]
+    (acc_ref ** 2).sum().backward()
+    acc = fused.fused_render(rays.cuda(), net, S, False)
+    (acc ** 2).sum().backward()
+    assert bool(torch.isfinite(acc).all())
+    assert rel_l2(acc.detach().cpu().numpy(), acc_ref.detach().numpy()) < 1e-5
+    assert rel_l2(net.encoder.embeddings.grad.cpu().numpy(), ref.encoder.embeddings.grad.numpy()) < 2e-4
+    # every sample sits in the (+,+,+) corner cell of each level: 8 rows per level at most
+    touched = (net.encoder.embeddings.grad.abs().sum(-1) > 0).sum().item()
+    assert 0 < touched <= 8 * 16
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_non_finite_rays_poison_their_own_results_only(prec):
+    """A NaN / Inf ray yields a NaN projection (the reference's NaN check, render.py:141-144, would print); the other rays of
+    the batch are untouched and no access leaves the table (positions are clamped before the cell index is taken)."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=7, oracle=False)
+    p = _abi.F32 if prec == "f32" else _abi.BF16
+    rays = crossing_rays(70, seed=4).cuda()
+    with torch.no_grad():
+        good = fused.fused_render(rays, net, 48, False, mlp_precision=p).clone()
+        bad = rays.clone()
+        bad[3, 0] = float("nan")
+        bad[17, 4] = float("inf")
+        bad[40, 6] = float("nan")
+        out = fused.fused_render(bad, net, 48, False, mlp_precision=p)
+    ok = torch.ones(70, dtype=torch.bool, device="cuda")
+    ok[[3, 17, 40]] = False
+    assert torch.equal(out[ok], good[ok])
+    assert not bool(torch.isfinite(out[~ok]).any())
+
+
+def test_batches_on_both_sides_of_the_scatter_switch_agree():
+    """AUTO picks atomics below 2^13 points per call and the binned scatter from there on: the same rays rendered as one
+    batch (binned) and as chunks (atomic) accumulate the same table gradient."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=8, oracle=False)
+    S, n = 64, 160                                               # 10 240 points in one call, 2 560 per chunk of 40
+    rays = crossing_rays(n, seed=6).cuda()
+    t_rand = torch.rand(n, S, device="cuda")
+    target = torch.rand(n, device="cuda") * 0.2
+    net.zero_grad()
+    acc = fused.fused_render(rays, net, S, True, t_rand=t_rand)
+    ((acc - target) ** 2).sum().backward()
+    whole = net.encoder.embeddings.grad.clone()
+    net.zero_grad()
+    for i in range(0, n, 40):
+        a = fused.fused_render(rays[i:i + 40], net, S, True, t_rand=t_rand[i:i + 40])
+        ((a - target[i:i + 40]) ** 2).sum().backward()
+    parts = net.encoder.embeddings.grad
+    assert rel_l2(parts.cpu().numpy(), whole.cpu().numpy()) < 2e-6
