@@ -144,6 +144,10 @@ class Trainer:
         elif self.group is not None:
             raise NotImplementedError("data-parallel training needs the fused engine (backend.engine: fused, n_fine: 0)")
         else:
+            if want_fused and noise_free and self.device.type == "cuda":      # say so instead of silently taking the slower path
+                why = "n_fine > 0 (two networks)" if self.n_fine > 0 else \
+                    "network / encoder shape outside the fused kernels (32 features, 4 layers of 32, skips [2], 1 output)"
+                print(f"[Trainer] {why}: using the module back end (autograd over the HIP operators + torch Linear layers)")
             self.optimizer = torch.optim.Adam(params=grad_vars, lr=cfg["train"]["lrate"], betas=(0.9, 0.999))
         self.lr_scheduler = _StepLR(self.optimizer, cfg["train"]["lrate_step"], cfg["train"]["lrate_gamma"])
 
