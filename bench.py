@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
                     help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_render_cfg.scatter_mode)")
     ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
+    ap.add_argument("--interleaved-levels", action="store_true",
+                    help="diagnostics: the encoder walks all levels of a point tile at once (NAF_CFG_LEVELS_INTERLEAVED)")
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
                          "stream, per-bucket Adam) with a world-size-1 process group")
@@ -228,7 +230,8 @@ def main():
         return NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"], table_dtype=tdt, seed=args.seed,
                          process_group=group, n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
                          scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
-                         cfg_flags=_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0, bucket_levels=buckets)
+                         cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0),
+                         bucket_levels=buckets)
 
     engine = make_engine(args.precision, pg)
     allreduce_bytes = engine.grad_flat.numel() * 4

@@ -185,6 +185,9 @@ typedef struct naf_render_cfg {
 #define NAF_CFG_EXPLICIT_DEPTHS 2u    /* the `t_rand` argument of the naf_render_* entry points holds the sample DEPTHS
                                          z[n_rays, S] themselves (the fine pass renders at the merged, sorted depths of
                                          naf_fine_depths, render.py:123-126); `perturb` is ignored                    */
+#define NAF_CFG_LEVELS_INTERLEAVED 4u /* diagnostics: the encoder walks all levels of a point tile at once instead of one
+                                         level at a time chip-wide -- same results, the cache behaviour of a kernel that
+                                         gathers every level of a tile (what a single fused gather+MLP kernel would see) */
 
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */

@@ -19,6 +19,7 @@ MLP_PARAMS = 4225
 SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED = 0, 1, 2
 CFG_PER_LEVEL_LAUNCHES = 1
 CFG_EXPLICIT_DEPTHS = 2
+CFG_LEVELS_INTERLEAVED = 4
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}

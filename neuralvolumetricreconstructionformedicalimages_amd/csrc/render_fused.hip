@@ -843,7 +843,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -858,8 +858,12 @@ __host__ __device__ constexpr uint32_t encode_points_per_thread(uint32_t C) { re
 template <typename TT, typename FT, uint32_t C, typename Src>
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base) {
-    const uint32_t level = level_base + blockIdx.y;
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, bool interleaved) {
+    // level-major by default: blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and that level's
+    // slice of the table stays in the L2s.  `interleaved` (NAF_CFG_LEVELS_INTERLEAVED, a diagnostic) puts the level in x instead:
+    // every XCD then walks all levels at once -- the cache behaviour of a kernel that gathers all levels of a point tile.
+    const uint32_t level = level_base + (interleaved ? blockIdx.x : blockIdx.y);
+    const uint32_t block_x = interleaved ? blockIdx.y : blockIdx.x, grid_x = interleaved ? gridDim.y : gridDim.x;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
@@ -867,8 +871,8 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     // several points per thread and iteration: 32 independent gathers in flight per lane (measured on the chest step,
     // C = 2: 1 / 2 / 4 / 8 points -> 3.28 / 2.99 / 2.81 / 2.90 ms)
     constexpr uint32_t kPts = encode_points_per_thread(C);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
+    const uint32_t stride = grid_x * blockDim.x;
+    for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
         float w[kPts][8], v[kPts][8][C];
 #pragma unroll
         for (uint32_t k = 0; k < kPts; ++k) {
@@ -907,12 +911,14 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
         for (uint32_t l = 0; l < cfg->L; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l);
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, false);
         }
         return check_launch("encode_kernel");
     }
-    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x((B + kPts - 1u) / kPts), cfg->L), dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u); }
+    const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
+    const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
+    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), interleaved ? dim3(cfg->L, gx) : dim3(gx, cfg->L), dim3(256), 0, s, src,
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, interleaved); }
     return check_launch("encode_kernel");
 }
 

@@ -30,6 +30,8 @@ echo sweep done
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 --sub-records 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
 timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 --sub-records 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
 timeout -k 10 300 python bench.py --force-dp --steps 10 --warmup 3 --cpu-seconds 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
+# the encoder with all levels of a point tile in flight at once (what a single fused gather+MLP kernel would do to the caches)
+timeout -k 10 300 python bench.py --interleaved-levels --steps 10 --warmup 3 --cpu-seconds 0 --sub-records 0 > $OUT/bench_interleaved.json 2> $OUT/interleaved.err
 echo modes done
 timeout -k 10 200 python tools/eval_bench.py > $OUT/eval.jsonl 2> $OUT/eval.err
 timeout -k 10 200 python tools/eval_bench.py --precision fp32 >> $OUT/eval.jsonl 2>> $OUT/eval.err

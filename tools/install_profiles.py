@@ -25,7 +25,7 @@ copy("bench_default.json", f"{TAG}_bench_default.json")
 copy("batch_sweep.jsonl", f"{TAG}_batch_sweep.jsonl")
 copy("bench_fp32_16384.json", f"{TAG}_bench_fp32_16384rays.json")
 copy("bench_per_level_16384.json", f"{TAG}_bench_per_level_16384rays.json")
-for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"), ("eval.jsonl", "eval_throughput.jsonl"),
+for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"), ("bench_interleaved.json", "bench_levels_interleaved_encoder.json"), ("eval.jsonl", "eval_throughput.jsonl"),
                  ("train_py.json", "train_py_throughput.json"), ("shapes.jsonl", "other_shapes_step_times.jsonl"),
                  ("psnr_16384_bf16.json", "chest_psnr_vs_time_16384rays.json"), ("psnr_16384_fp32.json", "chest_psnr_vs_time_16384rays_fp32.json"),
                  ("psnr_1024_bf16.json", "chest_psnr_vs_time_1024rays.json")):
