@@ -15,20 +15,31 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK (one process per GPU).  NAF_DIST_SHARE_GPU=1 is the rehearsal hook of a one-GPU box:
+    every rank then uses device 0 (together with NAF_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device)."""
+    if os.environ.get("NAF_DIST_SHARE_GPU") == "1":
+        return 0
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def init_from_env(device_type="cuda"):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank, group-or-None)."""
+    Returns (rank, world_size, local_rank, group-or-None).  Backend: RCCL ("nccl") on GPUs, gloo on the CPU;
+    NAF_DIST_BACKEND overrides it (rehearsals on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
         return 0, 1, local_rank, None
     if not dist.is_initialized():
+        backend = os.environ.get("NAF_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(local_device_index())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index()))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group(backend)
     return rank, world, local_rank, dist.group.WORLD
 
 

@@ -118,6 +118,8 @@ class Trainer:
         self.train_dloader = torch.utils.data.DataLoader(train_dset, batch_size=cfg["train"]["n_batch"])
         self.voxels = self.eval_dset.voxels if self.i_eval > 0 else None
 
+        if backend.get("seed") is not None:                # optional: reproducible initialisation (the reference seeds nothing)
+            torch.manual_seed(int(backend["seed"]))
         network = get_network(cfg["network"]["net_type"])
         net_cfg = {k: v for k, v in cfg["network"].items() if k != "net_type"}
         encoder = get_encoder(**cfg["encoder"])

@@ -101,6 +101,6 @@ if __name__ == "__main__":
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X: the NAF hot path has no CPU fallback")
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N train.py --config ...`
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    BasicTrainer(cfg, torch.device("cuda", local_rank)).start()
+    from neuralvolumetricreconstructionformedicalimages_amd.dist import local_device_index
+    torch.cuda.set_device(local_device_index())
+    BasicTrainer(cfg, torch.device("cuda", local_device_index())).start()
