@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--n-voxel", type=int, default=256)
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32"], default="bf16", help="table storage (fp32 = parity mode)")
+    ap.add_argument("--log2T", type=int, default=19, help="log2 of the hash-table rows per level (chest_50: 19, foot_50: 22)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--out", default=None)
@@ -43,9 +44,9 @@ def main():
     # projections of the whole scan (the "dataset"): 50 x 512 x 512 analytic line integrals
     projs = torch.cat([phantom.line_integrals(raygen.rays_for_projection(i), table) for i in range(len(angles))])
     torch.manual_seed(0)
-    enc = HashEncoder(3, 16, 2, 16, 19)
+    enc = HashEncoder(3, 16, 2, 16, args.log2T)
     net = DensityNetwork(enc, bound=0.3, num_layers=4, hidden_dim=32, skips=[2], out_dim=1, last_activation="sigmoid").to(dev)
-    engine = NAFEngine(net, 192, perturb=True, lr=args.lr, table_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32)
+    engine = NAFEngine(net, 192, perturb=True, lr=args.lr, table_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.precision])
     n_pix = projs.numel()
     valid = torch.nonzero(projs.abs() > 0).reshape(-1)              # tigre.py:356: only pixels that saw the object
     weight = torch.full((args.rays,), 1.0 / args.rays, device=dev)
