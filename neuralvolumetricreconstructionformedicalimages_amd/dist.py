@@ -60,11 +60,16 @@ def global_mean_weights(mask, group=None):
 
 
 def default_bucket_levels(num_levels):
-    """Level ranges in the order the gradient scatter finishes them: two halves, fine levels first.  The reducer then
-    still runs in full rounds of 256 workgroups (64 row buckets x 8 levels = 512), the first half's all-reduce hides behind
-    the second half's bin + reduce passes, and the exchange left exposed is the coarse half, whose dense levels are small
-    (22.5 of 57 MB at L = 16, T = 2^19)."""
+    """Level ranges in the order the gradient scatter finishes them: the fine half, the next quarter, the coarse quarter.
+    Every reducer launch still runs in full rounds of 256 workgroups (64 row buckets x 8 / 4 / 4 levels = 512 / 256 / 256),
+    each bucket's all-reduce hides behind the reduction of the buckets after it, and the exchange left exposed at the end is
+    the coarse quarter, whose dense levels are small (6.7 of 57 MB at L = 16, T = 2^19; 33.6 and 16.8 MB before it).
+    Measured on one GPU (bench.py --force-dp --buckets ...): 9.08-9.18 ms per step against 9.13-9.15 ms for two halves -- the
+    reducer itself is faster when the coarse levels, whose runs are uneven, do not share a launch with four hashed levels
+    (2.05 against 2.14 ms) -- with a last bucket a third the size."""
     L = int(num_levels)
+    if L >= 4:
+        return [(L // 2, L), (L // 4, L // 2), (0, L // 4)]
     return [(L // 2, L), (0, L // 2)] if L >= 2 else [(0, L)]
 
 

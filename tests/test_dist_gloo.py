@@ -102,8 +102,8 @@ def test_bucketed_exchange_equals_single_all_reduce():
         assert p.exitcode == 0
     for rank, table_ok, mlp_ok, slices, buckets in results:
         assert table_ok and mlp_ok
-        assert buckets == [(8, 16), (0, 8)]                          # fine levels first: their exchange hides behind the coarse half
-        assert slices[1][0] == 0 and slices[1][1] == slices[0][0]    # the two slices tile the table exactly once
+        assert buckets == [(8, 16), (4, 8), (0, 4)]                  # fine levels first: their exchange hides behind the coarser ones
+        assert slices[2][0] == 0 and slices[2][1] == slices[1][0] and slices[1][1] == slices[0][0]    # the slices tile the table exactly once
     with np.testing.assert_raises(ValueError):
         dist.grad_bucket_slices([0, 10, 20, 30], 2, [(0, 2), (1, 3)])           # overlap
     with np.testing.assert_raises(ValueError):
