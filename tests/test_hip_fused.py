@@ -553,11 +553,13 @@ def test_binned_scatter_large_batch_split_reducer():
     assert float((a - b).abs().max() / a.abs().max()) < 3e-2
 
 
-def test_binned_scatter_ragged_tail_tile_bf16():
-    """1850 points = 3.6 bin tiles of 512: the threads past the end of the batch must contribute nothing."""
+@pytest.mark.parametrize("log2T,n,S", [(16, 37, 50), (16, 41, 25), (20, 43, 97), (20, 64, 32), (21, 3, 683), (20, 1, 9)])
+def test_binned_scatter_ragged_tail_tile_bf16(log2T, n, S):
+    """Batches that end inside a pass-1 tile (1 024 points; 2 048 from T = 2^20 on, where pass 1 runs with 1 024 threads),
+    fill it exactly (64 x 32 = 2 048), or are smaller than one tile: the threads past the end of the batch must contribute
+    nothing, whatever the tile shape."""
     _abi, encoder, fused, network = _mods()
-    net, _ = _naf_pair(seed=13, log2T=16, scale=0.1)
-    n, S = 37, 50
+    net, _ = _naf_pair(seed=13, log2T=log2T, scale=0.1)
     rays = _rays(n, seed=41).cuda()
     t_rand = torch.rand(n, S, device="cuda")
     target = torch.rand(n, device="cuda") * 0.3
