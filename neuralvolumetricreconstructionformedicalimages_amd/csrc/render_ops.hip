@@ -156,7 +156,7 @@ fine_depths_kernel(const float *__restrict__ rays, const float *__restrict__ t_r
         // inverse-transform samples
         for (uint32_t j = lane; j < NF; j += 64u) {
             float uq;
-            if (det) uq = lin_t(j, NF);                      // torch.linspace(0, 1, N_fine)
+            if (det) uq = NF > 1u ? lin_t(j, NF) : 0.0f;     // torch.linspace(0, 1, N_fine); a single step is [0]
             else uq = u_rand ? u_rand[(size_t)r * NF + j] : jitter(seed ^ 0x9e3779b97f4a7c15ull, ray_base + r, j);
             uint32_t lo = 0u, hi = M;                        // searchsorted(cdf, u, right=True): entries <= u
             while (lo < hi) {

@@ -399,6 +399,21 @@ def test_fine_depths_kernel_matches_oracle_weights_sample_pdf_and_sort(perturb):
     assert bool((z_all[:, 1:] >= z_all[:, :-1]).all())
 
 
+def test_fine_depths_single_fine_sample_det():
+    """n_fine = 1 without jitter: torch.linspace(0, 1, 1) is [0] (render.py:224), so the one fine sample sits on the first bin
+    edge -- the mid-point of the first two coarse depths (a 0 / 0 in the kernel's own linspace until round 2)."""
+    _abi, encoder, fused, network = _mods()
+    net, _ = _naf_pair(seed=15)
+    n, S = 9, 12
+    rays = _rays(n, seed=3).cuda()
+    _, sigma, _ = fused.render_samples(rays, net, S, False)
+    z_all, _ = fused.fine_depths(rays, sigma, 1, False, det=True)
+    assert z_all.shape == (n, S + 1) and bool(torch.isfinite(z_all).all())
+    z = torch.stack([rays[:, 6] + (rays[:, 7] - rays[:, 6]) * t for t in torch.linspace(0, 1, S).tolist()], 1)
+    want = torch.sort(torch.cat([z, 0.5 * (z[:, :1] + z[:, 1:2])], 1), 1).values
+    np.testing.assert_allclose(z_all.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_fused_coarse_to_fine_render_matches_oracle():
     """render(..., net_fine, n_fine > 0) with both networks in the fused shape: coarse forward with per-sample sigma ->
     naf_fine_depths -> fine render at the explicit depths (NAF_CFG_EXPLICIT_DEPTHS), against the oracle's render_chunk;
