@@ -119,3 +119,30 @@ def test_batches_on_both_sides_of_the_scatter_switch_agree():
         ((a - target[i:i + 40]) ** 2).sum().backward()
     parts = net.encoder.embeddings.grad
     assert rel_l2(parts.cpu().numpy(), whole.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("n_streams", [2, 3])
+def test_engine_pipelined_over_streams_equals_the_single_stream_step(n_streams):
+    """NAFEngine(n_streams > 1) pipelines chunks of a ray batch over HIP streams, each lane with its own workspace and gradient
+    buffers that are folded at the end: same projection, loss and gradients as the single-stream step (chunking only
+    changes the fixed-point scale of each chunk's scatter and the order of a few fp32 sums)."""
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    S, n = 48, 500                                               # 500 rays in chunks of 96: 6 chunks, the last one ragged
+    rays = crossing_rays(n, seed=12).cuda()
+    t_rand = torch.rand(n, S, device="cuda")
+    target = torch.rand(n, device="cuda") * 0.2
+    weight = torch.full((n,), 1.0 / n, device="cuda")
+    out = {}
+    for tag, kw in (("one", {}), ("many", {"n_streams": n_streams, "chunk_rays": 96})):
+        net, _ = naf_pair(seed=21, oracle=False)
+        eng = NAFEngine(net, S, perturb=True, lr=1e-3, **kw)
+        acc = eng.backward(rays, target, weight, t_rand=t_rand).clone()
+        torch.cuda.synchronize()
+        out[tag] = (acc.cpu().numpy(), eng.emb_g.clone().cpu().numpy(), eng.mlp_g.clone().cpu().numpy(), float(eng.loss.item()))
+        eng.optimizer_step()                                     # and the step after it runs on clean buffers
+        acc2 = eng.backward(rays, target, weight, t_rand=t_rand)
+        assert bool(torch.isfinite(acc2).all())
+    assert rel_l2(out["many"][0], out["one"][0]) < 1e-6
+    assert rel_l2(out["many"][1], out["one"][1]) < 1e-5
+    assert rel_l2(out["many"][2], out["one"][2]) < 1e-5
+    assert abs(out["many"][3] - out["one"][3]) < 1e-6 * abs(out["one"][3])
