@@ -83,6 +83,52 @@ def test_two_rank_training_equals_single_process():
     np.testing.assert_allclose(results[0][3], loss, rtol=1e-3)
 
 
+def _empty_shard_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as td
+    from neuralvolumetricreconstructionformedicalimages_amd import dist
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    td.init_process_group("gloo")
+    group = td.group.WORLD
+    S = 64
+    engine = NAFEngine(_make(seed=0), S, perturb=True, lr=1e-2, process_group=group)
+    rays, t_rand, target, mask = _batch(n=3, S=S)
+    mask[:] = True
+    b, e = (0, 3) if rank == 0 else (3, 3)                        # rank 1 holds NO rays of this step
+    for _ in range(2):
+        w = dist.global_mean_weights(mask[b:e].cuda(), group)
+        engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, t_rand=t_rand[b:e].cuda().contiguous())
+    torch.cuda.synchronize()
+    out.put((rank, engine.emb.cpu().numpy(), engine.mlp.cpu().numpy()))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_a_rank_without_rays_still_takes_part_in_the_exchange():
+    """Three rays on two ranks with rank 1 holding none of them: its (empty) step still records the bucket events, joins every
+    all-reduce and applies the summed gradient, so both replicas end with the parameters of the single-process step."""
+    from neuralvolumetricreconstructionformedicalimages_amd import dist
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(collect(procs, q, len(procs)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    S = 64
+    engine = NAFEngine(_make(seed=0), S, perturb=True, lr=1e-2)
+    rays, t_rand, target, mask = _batch(n=3, S=S)
+    for _ in range(2):
+        engine.train_step(rays.cuda(), target.cuda(), torch.full((3,), 1.0 / 3, device="cuda"), t_rand=t_rand.cuda())
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+    np.testing.assert_allclose(results[0][2], engine.mlp.cpu().numpy(), rtol=0, atol=2e-4)
+    assert np.mean(np.abs(results[0][1] - engine.emb.cpu().numpy()) > 2e-3) < 1e-3
+
+
 def _rccl_worker(port, out):
     """World size 1 over the REAL backend ("nccl" = RCCL): the one-GPU test box cannot host two RCCL ranks, but a
     single-rank group drives exactly the code the 8-GPU run uses -- bucket events recorded by the library, the side
