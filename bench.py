@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
     ap.add_argument("--interleaved-levels", action="store_true",
                     help="diagnostics: the encoder walks all levels of a point tile at once (NAF_CFG_LEVELS_INTERLEAVED)")
+    ap.add_argument("--separate-adam", action="store_true",
+                    help="diagnostics: write the table gradient out and run the table's Adam pass as its own launch "
+                         "(default: the gradient reducer applies it, naf_render_train_adam)")
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
                          "stream, per-bucket Adam) with a world-size-1 process group")
@@ -231,7 +234,7 @@ def main():
                          process_group=group, n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
                          scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
                          cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0),
-                         bucket_levels=buckets)
+                         bucket_levels=buckets, fuse_table_adam=not args.separate_adam)
 
     engine = make_engine(args.precision, pg)
     allreduce_bytes = engine.grad_flat.numel() * 4

@@ -270,6 +270,30 @@ int naf_field_forward_grid(const double *start, const double *stop, const uint32
  * updated parameters (naf_dtype lp_dtype) is written too (16-bit tables keep an fp32 master).
  * If zero_grad != 0 the gradient buffer is cleared in the same pass.
  */
+/* One training step of the TABLE in one call (single-GPU steps): naf_render_train whose gradient reducer applies the Adam
+ * update to the table rows it has just finished instead of writing their gradient out for naf_adam_step to read back and
+ * clear -- the 57 MB (T=2^19) gradient table is then neither written, re-read nor zeroed.  Same results, bit for bit, as
+ * naf_render_train followed by naf_adam_step(param, exp_avg, exp_avg_sq, grad_embeddings, param_lp, lp_dtype, n, ...,
+ * zero_grad = 1): `grad_embeddings` must be all zero on entry and is all zero on return; the MLP gradient and the loss are
+ * written as usual (the caller steps the 4 225 MLP parameters with naf_adam_step).  Batches that take the atomic scatter
+ * (< 2^13 points) or split reducer launches run the two passes one after the other inside the call.
+ * `embeddings` is what the kernels gather from (the 16-bit shadow `param_lp` in 16-bit mode, `param` itself in fp32 mode). */
+typedef struct naf_table_adam {
+    float *param;          /* fp32 master table [rows, C] */
+    float *exp_avg;        /* Adam moments, same shape */
+    float *exp_avg_sq;
+    void *param_lp;        /* 16-bit shadow table or NULL */
+    int32_t lp_dtype;      /* NAF_F16 / NAF_BF16 when param_lp != NULL */
+    uint64_t n;            /* rows * C */
+    float lr, beta1, beta2, eps;
+    uint32_t step;         /* 1-based */
+    float grad_scale;      /* gradient multiplier (1 unless the loss was scaled) */
+} naf_table_adam;
+int naf_render_train_adam(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                          const void *embeddings, const int32_t *offsets, const float *mlp, float *acc, float *grad_embeddings,
+                          float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
+                          const naf_table_adam *adam, void *stream);
+
 int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype,
                   uint64_t n, float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale,
                   int zero_grad, void *stream);

@@ -52,6 +52,15 @@ class GradBuckets(ctypes.Structure):
 MAX_DRAW_SEGMENTS = 16
 
 
+class TableAdam(ctypes.Structure):
+    """struct naf_table_adam (include/naf_hip.h): the table's Adam state for naf_render_train_adam."""
+    _fields_ = [
+        ("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("param_lp", ctypes.c_void_p),
+        ("lp_dtype", ctypes.c_int32), ("n", ctypes.c_uint64), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
+        ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("step", ctypes.c_uint32), ("grad_scale", ctypes.c_float),
+    ]
+
+
 class ScanDraw(ctypes.Structure):
     """struct naf_scan_draw (include/naf_hip.h): valid-pixel lists of the projections a step draws from."""
     _fields_ = [
@@ -85,6 +94,8 @@ SIGNATURES = {
     "naf_render_train": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_train_bucketed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
                                          ctypes.POINTER(GradBuckets), _vp]),
+    "naf_render_train_adam": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
+                                     ctypes.POINTER(TableAdam), _vp]),
     "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_field_forward_grid": (_i32, [ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(ctypes.c_double * 3),
                                       ctypes.POINTER(ctypes.c_uint32 * 3), _vp, _vp, _vp, _vp, ctypes.POINTER(RenderCfg), _vp, _vp]),

@@ -4,23 +4,13 @@
 // One pass over (param, exp_avg, exp_avg_sq, grad): 16 B/lane vector accesses, optional low-precision
 // shadow copy of the parameters (16-bit hash tables keep an fp32 master) and optional in-place zeroing of
 // the gradient, so the 57 MB (T=2^19) / 422 MB (T=2^22) table is streamed exactly once per step.
+#include "adam_math.h"
 #include "naf_device.h"
 #include "naf_host.h"
 
+#include <cmath>
+
 namespace naf {
-
-struct AdamArgs {
-    float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale;
-};
-
-__device__ __forceinline__ float adam_one(float &p, float &m, float &v, float g, const AdamArgs &a) {
-    g *= a.grad_scale;
-    m = m + (g - m) * (1.0f - a.beta1);                    // torch: exp_avg.lerp_(grad, 1-beta1)
-    v = v * a.beta2 + (1.0f - a.beta2) * g * g;            // torch: exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;   // torch: (sqrt(v)/sqrt(bias2)).add_(eps)
-    p = p - (a.lr / a.bias1) * (m / denom);                // torch: param.addcdiv_(m, denom, -lr/bias1)
-    return p;
-}
 
 template <int LP>   // 0 none, 1 f16, 2 bf16
 __global__ void __launch_bounds__(256)
@@ -66,6 +56,25 @@ adam_kernel(float *__restrict__ param, float *__restrict__ m, float *__restrict_
 
 using namespace naf;
 
+AdamArgs naf::make_adam_args(float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale) {
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+    a.bias1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+    a.bias2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+    return a;
+}
+
+int naf::launch_adam(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype, uint64_t n,
+                     const AdamArgs &a, bool zero_grad, hipStream_t s) {
+    if (n == 0) return NAF_OK;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n / 4 + 255) / 256, 256u * 16u));
+    if (!param_lp) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<0>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, nullptr, n, a, zero_grad); }
+    else if (lp_dtype == NAF_F16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<1>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad); }
+    else if (lp_dtype == NAF_BF16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<2>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad); }
+    else return fail(NAF_ERR_UNSUPPORTED, "adam_step: lp_dtype must be NAF_F16 or NAF_BF16 when param_lp is given");
+    return check_launch("adam_kernel");
+}
+
 extern "C" int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype,
                              uint64_t n, float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale,
                              int zero_grad, void *stream) {
@@ -73,17 +82,6 @@ extern "C" int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, fl
     if (step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: step is 1-based");
     if (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad) & 15u)
         return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: buffers must be 16-byte aligned");
-    if (n == 0) return NAF_OK;
-    AdamArgs a;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
-    // torch computes the bias corrections in double on the host (torch/optim/adam.py _single_tensor_adam)
-    a.bias1 = (float)(1.0 - std::pow((double)beta1, (double)step));
-    a.bias2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n / 4 + 255) / 256, 256u * 16u));
-    hipStream_t s = (hipStream_t)stream;
-    if (!param_lp) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<0>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, nullptr, n, a, zero_grad != 0); }
-    else if (lp_dtype == NAF_F16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<1>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0); }
-    else if (lp_dtype == NAF_BF16) { ProfScope prof_("adam_kernel", s); hipLaunchKernelGGL(adam_kernel<2>, dim3(grid), dim3(256), 0, s, param, exp_avg, exp_avg_sq, grad, param_lp, n, a, zero_grad != 0); }
-    else return fail(NAF_ERR_UNSUPPORTED, "adam_step: lp_dtype must be NAF_F16 or NAF_BF16 when param_lp is given");
-    return check_launch("adam_kernel");
+    return launch_adam(param, exp_avg, exp_avg_sq, grad, param_lp, lp_dtype, n, make_adam_args(lr, beta1, beta2, eps, step, grad_scale),
+                       zero_grad != 0, (hipStream_t)stream);
 }

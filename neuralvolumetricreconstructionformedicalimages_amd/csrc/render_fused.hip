@@ -983,10 +983,22 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     return check_launch("mlp_grad_reduce_kernel");
 }
 
+// Workgroups a reducer launch over `nl` levels splits each bucket's tiles between: 1 when buckets x levels already fill the chip
+// twice over, more (with per-row atomics at the end) when a pass holds only a few levels.
+static uint32_t reducer_split(uint32_t NB, uint32_t nl) { return NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl))); }
+// The Adam tail (naf_render_train_adam) needs every reducer launch of the step unsplit, the binned scatter and level-major launches.
+static bool adam_tail_possible(const naf_render_cfg *cfg, const Workspace &w) {
+    if (!w.binned || per_level_launches(cfg)) return false;
+    const uint32_t NB = 1u << w.plan.log2_nb;
+    for (uint32_t l0 = 0; l0 < cfg->L; l0 += w.plan.levels_per_pass)
+        if (reducer_split(NB, std::min(w.plan.levels_per_pass, cfg->L - l0)) != 1u) return false;
+    return true;
+}
+
 template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                               const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
-                              const naf_grad_buckets *buckets, hipStream_t s) {
+                              const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr) {
     using FT = typename P::feat_t;
     constexpr uint32_t NT = BinShape<Rec>::kThreads, PTS = BinShape<Rec>::kPoints;
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
@@ -1004,7 +1016,8 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     if constexpr (kHasBig) {
         if (big) bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvFew>;
     }
-    auto red = scatter_reduce_kernel<C, Rec>;
+    auto red = adam != nullptr ? scatter_reduce_kernel<C, Rec, true> : scatter_reduce_kernel<C, Rec, false>;
+    const AdamTail tail = adam != nullptr ? *adam : AdamTail{};
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;
     const uint32_t bin_lds = (2u * NB + 4u) * 4u + plan.slots * (uint32_t)sizeof(Rec);
@@ -1025,9 +1038,10 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
         ProfScope prof_(per_level ? level_name(red_names, l0 + ly0) : "scatter_reduce_kernel", s);
         // keep >= ~1024 reducer workgroups in flight: with one or two levels per pass split each bucket's tiles.
         // (A reducer workgroup owns a CU's LDS, so 256 run at a time: 512 or more unsplit ones already come in full rounds.)
-        const uint32_t n_split = NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl)));
+        const uint32_t n_split = reducer_split(NB, nl);
+        if (adam != nullptr && n_split != 1u) return fail(NAF_ERR_LAUNCH, "binned scatter: the Adam tail needs unsplit reducer launches");
         hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                           grad_table, w.gmax, l0, ly0, plan);
+                           grad_table, w.gmax, l0, ly0, plan, tail);
         return check_launch("scatter_reduce_kernel");
     };
     if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {
@@ -1055,12 +1069,13 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                     const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
-                                    const naf_grad_buckets *buckets = nullptr) {
+                                    const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
-        return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s);
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam);
+        return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam);
     }
+    if (adam != nullptr) return fail(NAF_ERR_LAUNCH, "hash backward: the Adam tail needs the binned scatter");
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("hash_backward_kernel_L");
         for (uint32_t l = lv_begin; l < lv_end; ++l) {
@@ -1080,9 +1095,11 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 // bucket is still being binned and reduced).
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
-                             const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s) {
+                             const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s,
+                             const AdamTail *adam = nullptr) {
     if (w.binned && hipMemsetAsync(w.overflow, 0, 33 * 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
-    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s);
+    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam);
+    if (adam != nullptr) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: the Adam tail cannot be combined with gradient buckets");
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
         return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
     for (uint32_t b = 0; b < buckets->n_buckets; ++b) {
@@ -1118,23 +1135,31 @@ static int render_forward_impl(const float *rays, const float *t_rand, const voi
 template <typename P, uint32_t C>
 static int render_backward_impl(const float *rays, const float *t_rand, const float *grad_acc, const void *emb, const int32_t *offsets,
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
-                                void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s) {
+                                void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
+                                const AdamTail *adam = nullptr) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
+    AdamTail tail;
+    if (adam != nullptr) {                                   // the overflow counters live in this call's workspace
+        tail = *adam;
+        tail.overflow = w.overflow;
+        adam = &tail;
+    }
     if (!features_valid)
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
     if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, n_rays, B, cfg, s)) return rc;
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam);
 }
 
 template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
-                             uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s) {
+                             uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
+                             const AdamTail *adam = nullptr) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
     const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
     {   // the partial sums live behind grad_acc in the workspace (carve reserves 256 bytes for them)
@@ -1145,7 +1170,7 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
         if (blocks > 1u && loss_out != nullptr) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, blocks, loss_out);
     }
     if (int rc = check_launch("loss_grad_kernel")) return rc;
-    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s);
+    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam);
 }
 
 template <typename P, uint32_t C>
@@ -1279,7 +1304,8 @@ static int check_buckets(const naf_grad_buckets *b, uint32_t L) {
 static int render_train_entry(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                              const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream) {
+                              const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream,
+                              const AdamTail *adam = nullptr) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
@@ -1297,7 +1323,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
         return NAF_OK;
     }
     NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream);
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
@@ -1315,6 +1341,35 @@ extern "C" int naf_render_train_bucketed(const float *rays, const float *t_rand,
     if (!buckets) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_bucketed: null buckets");
     return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
                               n_rays, cfg, workspace, buckets, stream);
+}
+
+static_assert(kAdamLpF16 == NAF_F16 && kAdamLpBF16 == NAF_BF16, "adam_math.h mirrors naf_dtype");
+
+extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                     const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                     float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                     const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream) {
+    if (!adam) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null adam");
+    if (!adam->param || !adam->exp_avg || !adam->exp_avg_sq || !grad_embeddings) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null pointer");
+    if (adam->step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: step is 1-based");
+    if (adam->param_lp != nullptr && adam->lp_dtype != NAF_F16 && adam->lp_dtype != NAF_BF16)
+        return fail(NAF_ERR_UNSUPPORTED, "render_train_adam: lp_dtype must be NAF_F16 or NAF_BF16 when param_lp is given");
+    if (((uintptr_t)adam->param | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq | (uintptr_t)grad_embeddings) & 15u)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: buffers must be 16-byte aligned");
+    if (int rc = check_cfg(cfg, "render_train_adam")) return rc;
+    AdamTail tail;
+    tail.param = adam->param; tail.m = adam->exp_avg; tail.v = adam->exp_avg_sq;
+    tail.lp = adam->param_lp; tail.lp_dtype = adam->lp_dtype; tail.overflow = nullptr;
+    tail.a = make_adam_args(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale);
+    const uint64_t n_points = (uint64_t)n_rays * cfg->n_samples;
+    if (n_rays != 0 && workspace != nullptr && n_points < (1ull << 31) && adam_tail_possible(cfg, carve(workspace, cfg, n_points)))
+        return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
+                                  n_rays, cfg, workspace, nullptr, stream, &tail);
+    // small batches (atomic scatter), split reducer launches, per-level diagnostics, empty batches: the two passes one after the other
+    if (int rc = render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
+                                    n_rays, cfg, workspace, nullptr, stream)) return rc;
+    return launch_adam(adam->param, adam->exp_avg, adam->exp_avg_sq, grad_embeddings, adam->param_lp, adam->lp_dtype, adam->n, tail.a,
+                       true, (hipStream_t)stream);
 }
 
 extern "C" int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,

@@ -45,6 +45,7 @@
 // only (lds_barrier), and the global loads of the loop are consumed before the stores.
 #pragma once
 
+#include "adam_math.h"
 #include "naf_device.h"
 
 namespace naf {
@@ -232,12 +233,16 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = w[c] * g[q][ch];
             });
-            on[q] = true;
+            // padding threads of the last tile (clones of the last point, zero gradient) emit nothing: if that point sits on a
+            // face of the volume its x pairs are unpaired on every level from 2 on, and 8 records per clone would fill the
+            // block and push the tile's real records out to atomics
+            on[q] = valid[q];
             if (merging) {
                 // Merge each run of equal cells with a segmented inclusive scan; only the last lane of a run emits.  Runs
                 // are cut at 16-lane rows: the scan then moves its operands with DPP row shifts (a modifier of the VALU
                 // instruction) instead of 6 x 16 trips through the LDS crossbar (ds_bpermute).
-                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2];        // merging levels have < 2^16 cells per axis
+                // (padding lanes get a cell key of their own -- bit 31 of c_hi -- so that they never share a run with real points)
+                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2] | (valid[q] ? 0u : 0x80000000u);    // merging levels have < 2^16 cells per axis
                 const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
                 const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
                 const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
@@ -254,7 +259,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 fold(std::integral_constant<uint32_t, 2>{});
                 fold(std::integral_constant<uint32_t, 4>{});
                 fold(std::integral_constant<uint32_t, 8>{});
-                on[q] = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+                on[q] = valid[q] && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
             }
             // x-neighbour corners (2k, 2k+1) travel together when their rows share a 64-row block; otherwise (1.6 % of the
             // pairs) the record keeps both value halves with mask 0 and phase C splits it into two single records
@@ -380,11 +385,14 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 // gfx950 against 2.46 for ds_add_f64 and 0.33 for ds_add_f32 (tools/lds_atomic_bench.hip).  Integer addition is
 // associative, so the reduction is bit-reproducible from run to run.  The scale follows the largest feature gradient of
 // the step (fixed_shift): 31 significant bits below it, 28 bits of headroom above for the sum of merged records.
-template <uint32_t C, typename Rec>
+// kAdam (naf_render_train_adam, single-GPU steps): the workgroup is the sole owner of its rows and has their finished sums in
+// LDS, so instead of writing the gradient out for a separate Adam pass to read back and clear it applies the update itself --
+// the 57 MB gradient table is then neither written, re-read nor zeroed (only rows that pass 1 reached with atomics are).
+template <uint32_t C, typename Rec, bool kAdam = false>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base,
-                      uint32_t ly_begin, BinPlan plan) {
+                      uint32_t ly_begin, BinPlan plan, AdamTail adam) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift(gbits);
@@ -507,7 +515,35 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     __syncthreads();
     float *__restrict__ gg = grad_table + (size_t)off * C;
     const float nan = __builtin_nanf("");
-    if (gridDim.z == 1u) {
+    if constexpr (kAdam) {
+        // Same traversal as below (64 consecutive rows x C per step, coalesced on every array).  A level whose tiles overflowed
+        // their blocks has contributions in the gradient table already (atomics of pass 1): they are added and cleared here.
+        const bool spilled = adam.overflow[1u + level] != 0u;
+        float *__restrict__ pp = adam.param + (size_t)off * C;
+        float *__restrict__ pm = adam.m + (size_t)off * C;
+        float *__restrict__ pv = adam.v + (size_t)off * C;
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
+            const uint32_t local = i / C, ch = i - local * C;
+            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            if (row < T) {
+                const size_t e = (size_t)row * C + ch;
+                float g = poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
+                if (spilled) {
+                    const float extra = gg[e];
+                    if (extra != 0.0f) { g = extra + g; gg[e] = 0.0f; }          // the order of the separate route: table += sum
+                }
+                float p = pp[e], m = pm[e], v = pv[e];
+                adam_one(p, m, v, g, adam.a);
+                pp[e] = p; pm[e] = m; pv[e] = v;
+                if (adam.lp != nullptr) {
+                    const size_t el = (size_t)off * C + e;
+                    if (adam.lp_dtype == kAdamLpF16) reinterpret_cast<_Float16 *>(adam.lp)[el] = (_Float16)p;
+                    else reinterpret_cast<uint16_t *>(adam.lp)[el] = f32_to_bf16(p);
+                }
+            }
+        }
+    } else if (gridDim.z == 1u) {
         // sole owner, and the bucket's local rows 64 k .. 64 k + 63 are 64 consecutive table rows: add the sums in place,
         // coalesced (64 x C floats per block)
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {

@@ -24,7 +24,7 @@ from . import fused
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
                  mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384, scatter_mode=None, cfg_flags=None,
-                 bucket_levels=None):
+                 bucket_levels=None, fuse_table_adam=True):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -40,6 +40,9 @@ class NAFEngine:
         self.rays_seen = 0
         self.process_group = process_group
         self.scatter_mode, self.cfg_flags = scatter_mode, cfg_flags     # None: fused.scatter_mode() default (auto)
+        # single-GPU, single-stream steps let the gradient reducer apply the table's Adam update itself (naf_render_train_adam:
+        # the gradient table is neither written, re-read nor cleared; bit-identical to backward() + optimizer_step())
+        self.fuse_table_adam = bool(fuse_table_adam)
 
         # ---- flat fp32 master parameters; module parameters become views ---------------------------------
         self.emb = enc.embeddings.data.float().contiguous()
@@ -310,13 +313,40 @@ class NAFEngine:
     def train_step(self, rays, target, weight, t_rand=None, ray_base=0):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync)."""
-        self.backward(rays, target, weight, t_rand, ray_base)
-        if self._dp is not None:
-            self._exchange_and_step()
+        n = rays.shape[0]
+        if self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
+            self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
         else:
-            self.optimizer_step()
-        self.rays_seen += rays.shape[0]
+            self.backward(rays, target, weight, t_rand, ray_base)
+            if self._dp is not None:
+                self._exchange_and_step()
+            else:
+                self.optimizer_step()
+        self.rays_seen += n
         return self.loss
+
+    def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base):
+        """backward() + optimizer_step() in two library calls: naf_render_train_adam (the reducer finishes every table row with
+        its Adam update) and the Adam pass over the 4 225 MLP parameters."""
+        n = rays.shape[0]
+        if self.acc is None or self.acc.numel() < n:
+            self.acc = torch.empty(n, device=self.device)
+        self.loss.zero_()
+        cfg = self._cfg(ray_base)                              # the jitter seed of step k, as in backward()
+        self.step_count += 1                                   # ... and the Adam step count k + 1, as in optimizer_step()
+        ws = fused.workspace(cfg, n * self.n_samples, self.device)
+        b1, b2 = self.betas
+        st = _abi.TableAdam()
+        st.param, st.exp_avg, st.exp_avg_sq = self.emb.data_ptr(), self.emb_m.data_ptr(), self.emb_v.data_ptr()
+        st.param_lp = None if self.emb_lp is None else self.emb_lp.data_ptr()
+        st.lp_dtype = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
+        st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = self.emb.numel(), self.lr, b1, b2, self.eps, self.step_count, 1.0
+        _abi.check(_abi.lib().naf_render_train_adam(
+            _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
+            _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
+            ctypes.byref(cfg), _abi.ptr(ws), ctypes.byref(st), _abi.stream_ptr()), "render_train_adam")
+        fused._bump(self.device)
+        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
 
     # ---- optimiser state in torch.optim.Adam's layout (checkpoint compatibility, trainer.py:118-126) ---------
     def optimizer_state_dict(self):
