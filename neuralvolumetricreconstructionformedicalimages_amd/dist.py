@@ -61,7 +61,8 @@ def global_mean_weights(mask, group=None):
 
 def default_bucket_levels(num_levels):
     """Level ranges in the order the gradient scatter finishes them: the fine half, the next quarter, the coarse quarter.
-    Every reducer launch still runs in full rounds of 256 workgroups (64 row buckets x 8 / 4 / 4 levels = 512 / 256 / 256),
+    Every reducer launch still runs in full rounds of 256 workgroups (64 row buckets x 8 levels = 512; the two launches of
+    four levels split each bucket's tiles four ways, 4 x 256, and finish their rows with one atomic each),
     each bucket's all-reduce hides behind the reduction of the buckets after it, and the exchange left exposed at the end is
     the coarse quarter, whose dense levels are small (6.7 of 57 MB at L = 16, T = 2^19; 33.6 and 16.8 MB before it).
     Measured on one GPU (bench.py --force-dp --buckets ...): 9.08-9.18 ms per step against 9.13-9.15 ms for two halves -- the
