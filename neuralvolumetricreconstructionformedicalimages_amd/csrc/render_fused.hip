@@ -484,10 +484,10 @@ loss_sum_kernel(const float *__restrict__ partial, uint32_t n, float *__restrict
 
 // ---- 3b: MLP backward on 16-point tiles (bf16 mode, C = 2; field_mlp16.h) ----------------------------------------
 // Same outputs as mlp_backward_kernel (dfeat, one dW slab per workgroup, max |dfeat|) at two or more waves per SIMD.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)                     // 168 VGPRs (11 spilled dwords): three waves per SIMD
 mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                       const float *__restrict__ grad_acc, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
-                      uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act) {
+                      uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act, uint32_t log2_parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Mlp16Shared::build(smem, mlp, 8);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
@@ -517,25 +517,32 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     uint32_t dmax = 0u;                                      // see mlp_backward_kernel
     f32x4v dw3lo = zero4, dw3hi = zero4;
 
+    // A work item is one ray, or one of 2^log2_parts consecutive tile ranges of a ray when there are fewer rays than waves
+    // (1 024-ray steps: two waves per ray; the backward of a sample needs nothing of its ray but d acc, so the ranges are
+    // independent): twice the waves per SIMD to hide the latency of the dependent MFMA chain behind.
     const uint32_t S = src.S, tiles = (S + 15u) / 16u;
+    const uint32_t n_items = n_rays << log2_parts, part_mask = (1u << log2_parts) - 1u;
+    auto first_tile = [&](uint32_t item) { return ((item & part_mask) * tiles) >> log2_parts; };
     Feat16Raw ahead;
-    if (wave < n_rays) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
-    for (uint32_t r = wave; r < n_rays; r += n_waves) {
+    if (wave < n_items) load_feat16(feat, B, (wave >> log2_parts) * S + min(16u * first_tile(wave) + c, S - 1u), g, ahead);
+    for (uint32_t item = wave; item < n_items; item += n_waves) {
+        const uint32_t r = item >> log2_parts, k_begin = first_tile(item), k_end = (((item & part_mask) + 1u) * tiles) >> log2_parts;
         const float *ray = src.rays + (size_t)r * 8;
         const float near = ray[6], far = ray[7];
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
         const float dacc = grad_acc[r];
         if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
 
-        for (uint32_t k = 0; k < tiles; ++k) {
+        for (uint32_t k = k_begin; k < k_end; ++k) {
             const uint32_t s = 16u * k + c;
             const bool valid = s < S;
             const uint32_t p = r * S + (valid ? s : S - 1u);
             const Feat16Raw now = ahead;
-            {
-                const bool more = k + 1u < tiles;
-                const uint32_t rn = more ? r : (r + n_waves < n_rays ? r + n_waves : r);
-                const uint32_t sn = more ? s + 16u : c;
+            {   // the next tile of this item, or the first tile of the wave's next item (a harmless reload at the very end)
+                const bool more = k + 1u < k_end;
+                const uint32_t next = item + n_waves < n_items ? item + n_waves : item;
+                const uint32_t rn = more ? r : next >> log2_parts;
+                const uint32_t sn = more ? s + 16u : 16u * first_tile(next) + c;
                 load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
             }
             const bf16x8 x0f = feat16_operand(now);
@@ -728,6 +735,7 @@ mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float 
 
 // ---- host side ----------------------------------------------------------------------------------------------
 constexpr uint32_t kBackwardBlocks = 512;   // 2 workgroups of 4 waves per CU; also the number of dW slabs
+constexpr uint32_t kBackwardBlocks16 = 768; // the 16-point bf16 kernel fits three workgroups per CU (0.89 -> 0.835 ms at 65 536 rays)
 
 // Raise a kernel's dynamic-LDS limit.  The attribute is per device and the call is a cheap host-side table update, so it
 // is simply made before every launch of a kernel that may need more than the default: no cached flag to go stale when the
@@ -808,7 +816,7 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
 static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points) {
     const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
     const size_t feat_bytes = ((size_t)n_points * cfg->L * cfg->C * esz + 255) & ~(size_t)255;
-    const size_t slab_bytes = (size_t)kBackwardBlocks * kSlabStride * 4;
+    const size_t slab_bytes = (size_t)std::max(kBackwardBlocks, kBackwardBlocks16) * kSlabStride * 4;
     const size_t n_rays_max = (size_t)(n_points / std::max<uint32_t>(cfg->n_samples, 1u)) + 1;
     Workspace w;
     w.feat = (unsigned char *)base;
@@ -963,9 +971,13 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
             const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
             const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
             if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
-            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
+            // fewer rays than the 3 072 waves of the launch: up to 8 tile ranges per ray (never more ranges than tiles)
+            const uint32_t tiles = (cfg->n_samples + 15u) / 16u;
+            uint32_t log2_parts = 0;
+            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= 4ull * kBackwardBlocks16 && (2u << log2_parts) <= tiles) ++log2_parts;
+            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((((uint64_t)n_rays << log2_parts) + 3) / 4, kBackwardBlocks16));
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
-                               grad_acc, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
+                               grad_acc, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation, log2_parts); }
             if (int rc = check_launch("mlp16_backward_kernel")) return rc;
             { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + kReduceParams - 1) / kReduceParams), dim3(256), 0, s, slabs, grid16, grad_mlp); }
             return check_launch("mlp_grad_reduce_kernel");
