@@ -971,10 +971,11 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
             const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
             const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
             if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
-            // fewer rays than the 3 072 waves of the launch: up to 8 tile ranges per ray (never more ranges than tiles)
+            // fewer rays than the chip has SIMDs (1 024): up to 8 tile ranges per ray, never more ranges than tiles, so that every
+            // SIMD gets a wave (from one wave per SIMD on, more items only mean more slabs to fold: measured at 1 024 rays)
             const uint32_t tiles = (cfg->n_samples + 15u) / 16u;
             uint32_t log2_parts = 0;
-            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= 4ull * kBackwardBlocks16 && (2u << log2_parts) <= tiles) ++log2_parts;
+            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= 1024u && (2u << log2_parts) <= tiles) ++log2_parts;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((((uint64_t)n_rays << log2_parts) + 3) / 4, kBackwardBlocks16));
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
                                grad_acc, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation, log2_parts); }
