@@ -117,7 +117,7 @@ class ScanSampler:
         self.raygen, self.projs, self.seed = raygen, projs, int(seed)       # projs: [n_proj * H * W] fp32, resident
         hw = raygen.pixels_per_projection
         self.n_proj = projs.numel() // hw
-        self.valid = [(torch.nonzero(projs[i * hw:(i + 1) * hw] > 0, as_tuple=False).reshape(-1) + i * hw).contiguous()
+        self.valid = [(torch.nonzero(projs[i * hw:(i + 1) * hw].abs() > 0, as_tuple=False).reshape(-1) + i * hw).contiguous()
                       for i in range(self.n_proj)]
 
     def draw(self, step, n, rays_out):
@@ -136,6 +136,110 @@ class ScanSampler:
         return (targets[0] if len(targets) == 1 else torch.cat(targets)), rays_out
 
 
+class ChestScan:
+    """chest_50 synthetic scan resident in HBM: geometry, poses, all 50 x 512 x 512 measured values, the per-projection
+    valid-pixel lists, and (for the PSNR half of the metric) the 256^3 ground-truth volume with its voxel-grid axes."""
+
+    def __init__(self, device, sampler_seed, with_volume=True):
+        from neuralvolumetricreconstructionformedicalimages_amd import phantom
+        from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
+        self.device = device
+        self.geo = geo = ConeGeometry(phantom.scan_geometry(CHEST["n_voxel"], "cone"))
+        angles = np.linspace(0, np.pi, CHEST["n_proj"] + 1)[:-1]          # generateData.py:175, totalAngle 180
+        self.raygen = raygen = RayGenerator(geo, angles, device)
+        table = phantom.ellipsoid_table(seed=0, extent=float(geo.sVoxel[0]) / 2)
+        hw = raygen.pixels_per_projection
+        self.projs = torch.empty(raygen.n_projections * hw, device=device)
+        for i in range(raygen.n_projections):
+            r = raygen.rays_for_projection(i)
+            for j in range(0, hw, 1 << 16):
+                self.projs[i * hw + j:i * hw + j + (1 << 16)] = phantom.line_integrals(r[j:j + (1 << 16)], table)
+        self.sampler = ScanSampler(raygen, self.projs, sampler_seed)
+        self.image = phantom.volume(geo, table, device=device).double() if with_volume else None
+        s = geo.sVoxel / 2 - geo.dVoxel / 2                               # voxel centres, tigre.py:388-400
+        self.axes = ([-float(v) for v in s], [float(v) for v in s], [int(v) for v in geo.nVoxel])
+
+    def volume_psnr(self, net):
+        """Reconstructed-volume PSNR of train.py:246-270: the whole 256^3 grid queried through `naf_field_forward_grid`,
+        scored like `get_psnr_3d` (util.py:55-84: float64, 20 log10(1 / rmse), PIXEL_MAX = 1) -- evaluated on the device."""
+        from neuralvolumetricreconstructionformedicalimages_amd.fused import field_query_grid
+        vol = field_query_grid(net, *self.axes).double()
+        mse = float((vol - self.image).square().mean().item())
+        return 100.0 if mse <= 0.0 else 20.0 * float(np.log10(1.0 / np.sqrt(mse)))
+
+
+def make_chest_engine(device, precision="bf16", lr=None, group=None, seed=0, **kw):
+    from neuralvolumetricreconstructionformedicalimages_amd.encoder import HashEncoder
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
+    torch.manual_seed(seed)                                           # identical initial weights on every rank
+    enc = HashEncoder(3, CHEST["num_levels"], CHEST["level_dim"], CHEST["base_resolution"], CHEST["log2_hashmap_size"])
+    net = DensityNetwork(enc, bound=CHEST["bound"], num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
+                         last_activation="sigmoid").to(device)
+    tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+    return NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"] if lr is None else lr, table_dtype=tdt, seed=seed,
+                     process_group=group, **kw)
+
+
+def step_weights(n, device, world=1):
+    """Per-ray loss weights of a step of n rays: the reference's sum of 200-ray chunk means at its own batch size
+    (train.py:69,127), the plain (global) mean for every other batch."""
+    from neuralvolumetricreconstructionformedicalimages_amd.loss import chunk_mean_weights
+    if n == CHEST["yaml_rays"] and world == 1:
+        return chunk_mean_weights(torch.ones(n, dtype=torch.bool, device=device), 200, "chunk_sum"), "chunk_sum (sum of 200-ray chunk means)"
+    return torch.full((n,), 1.0 / (n * world), device=device), "global mean"
+
+
+def psnr_race(scan, n_rays, lr, precision="bf16", thresholds=(30.0, 35.0, 38.0), max_train_s=12.0, burst_s=0.1, seed=0):
+    """The PSNR half of the metric as a race: train chest_50 from scratch with steps of `n_rays` rays at learning rate `lr`
+    and record the TRAINING time (seconds inside train steps: pixel draw + ray generation + forward + backward + Adam, evaluation
+    excluded), the rays and the steps after which the reconstructed 256^3 volume first reaches each PSNR threshold.  The volume
+    is evaluated between bursts of about `burst_s` seconds of training, so a reported time is an upper bound by at most one
+    burst.  Also returns the sustained throughput over the whole race (rays / training seconds, >= 2 s unless the last
+    threshold falls earlier)."""
+    device = scan.device
+    rays = torch.empty(n_rays, 8, device=device)
+    weight, loss_name = step_weights(n_rays, device)
+
+    def run(engine, first, count):
+        for i in range(first, first + count):
+            target, _ = scan.sampler.draw(i, n_rays, rays)
+            engine.train_step(rays, target, weight, ray_base=i * n_rays)
+
+    scratch = make_chest_engine(device, precision, lr, seed=seed)      # sizes the workspace, measures the step for the burst length
+    run(scratch, 0, 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(scratch, 3, 10)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 10
+    del scratch
+    burst = max(1, int(round(burst_s / est)))
+    engine = make_chest_engine(device, precision, lr, seed=seed)
+    curve = [{"train_s": 0.0, "steps": 0, "psnr_db": round(scan.volume_psnr(engine.net), 3)}]
+    reached, pending = {}, sorted(thresholds)
+    t_train, steps = 0.0, 0
+    while pending and t_train < max_train_s:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(engine, steps, burst)
+        torch.cuda.synchronize()
+        t_train += time.perf_counter() - t0
+        steps += burst
+        psnr = scan.volume_psnr(engine.net)
+        curve.append({"train_s": round(t_train, 4), "steps": steps, "psnr_db": round(psnr, 3)})
+        while pending and psnr >= pending[0]:
+            reached[f"{pending.pop(0):g}dB"] = {"train_s": round(t_train, 4), "steps": steps, "rays": steps * n_rays}
+    for th in pending:
+        reached[f"{th:g}dB"] = None                                     # not reached inside max_train_s
+    keep = curve[::max(1, len(curve) // 24)]
+    if keep[-1] is not curve[-1]:
+        keep.append(curve[-1])
+    return {"rays_per_step": n_rays, "lr": lr, "precision": precision, "loss": loss_name, "burst_steps": burst,
+            "time_to_psnr": reached, "final": curve[-1], "train_seconds": round(t_train, 4), "steps": steps,
+            "sustained_rays_per_s": steps * n_rays / t_train, "ms_per_step": round(t_train / steps * 1e3, 4), "curve": keep}
+
+
 def main():
     # ONE JSON line on stdout: libraries that print to file descriptor 1 (RCCL's version banner at the first collective) are
     # sent to stderr for the whole run; the result line is written to the real stdout at the end.
@@ -150,11 +254,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--sub-records", type=int, default=1, help="0: skip the fp32-parity-mode and 1024-ray sub-records (N = 1 only)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=None, help="Adam learning rate (default: chest_50.yaml's 1e-3)")
+    ap.add_argument("--psnr-seconds", type=float, default=12.0,
+                    help="training-time budget of each PSNR race (time to 30 / 35 / 38 dB volume PSNR; N = 1 only; 0 disables)")
     ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
                     help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_render_cfg.scatter_mode)")
     ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
     ap.add_argument("--interleaved-levels", action="store_true",
                     help="diagnostics: the encoder walks all levels of a point tile at once (NAF_CFG_LEVELS_INTERLEAVED)")
+    ap.add_argument("--two-gathers", action="store_true",
+                    help="diagnostics: the encoder fetches x-neighbour corners with two gathers instead of one 16-byte window "
+                         "(NAF_CFG_ENCODE_TWO_GATHERS)")
     ap.add_argument("--separate-adam", action="store_true",
                     help="diagnostics: write the table gradient out and run the table's Adam pass as its own launch "
                          "(default: the gradient reducer applies it, naf_render_train_adam)")
@@ -194,47 +304,29 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
-    from neuralvolumetricreconstructionformedicalimages_amd import _abi, phantom
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi
     from neuralvolumetricreconstructionformedicalimages_amd.build import source_fingerprint
-    from neuralvolumetricreconstructionformedicalimages_amd.encoder import HashEncoder
-    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
-    from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
-    from neuralvolumetricreconstructionformedicalimages_amd.loss import chunk_mean_weights
-    from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
 
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     # ---- chest_50 scan, resident in HBM: geometry, poses, all 50 x 512 x 512 measured values -----------------------
-    geo = ConeGeometry(phantom.scan_geometry(CHEST["n_voxel"], "cone"))
-    angles = np.linspace(0, np.pi, CHEST["n_proj"] + 1)[:-1]          # generateData.py:175, totalAngle 180
-    raygen = RayGenerator(geo, angles, device)
-    table = phantom.ellipsoid_table(seed=0, extent=float(geo.sVoxel[0]) / 2)
-    hw = raygen.pixels_per_projection
-    projs = torch.empty(raygen.n_projections * hw, device=device)
-    for i in range(raygen.n_projections):
-        r = raygen.rays_for_projection(i)
-        for j in range(0, hw, 1 << 16):
-            projs[i * hw + j:i * hw + j + (1 << 16)] = phantom.line_integrals(r[j:j + (1 << 16)], table)
-    sampler = ScanSampler(raygen, projs, 1234 + rank)                 # each rank draws its own shard
-    log(f"scan resident: {raygen.n_projections} projections, {min(v.numel() for v in sampler.valid)}.."
+    scan = ChestScan(device, 1234 + rank, with_volume=(rank == 0))    # each rank draws its own shard
+    sampler = scan.sampler
+    log(f"scan resident: {scan.raygen.n_projections} projections, {min(v.numel() for v in sampler.valid)}.."
         f"{max(v.numel() for v in sampler.valid)} valid pixels each")
 
     def make_engine(precision, group):
-        torch.manual_seed(args.seed)                                   # identical initial weights on every rank
-        enc = HashEncoder(3, CHEST["num_levels"], CHEST["level_dim"], CHEST["base_resolution"], CHEST["log2_hashmap_size"])
-        net = DensityNetwork(enc, bound=CHEST["bound"], num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
-                             last_activation="sigmoid").to(device)
-        tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         buckets = None
         if args.buckets and group is not None:
             buckets = [tuple(int(v) for v in b.split("-")) for b in args.buckets.split(",")]
-        return NAFEngine(net, CHEST["n_samples"], perturb=True, lr=CHEST["lr"], table_dtype=tdt, seed=args.seed,
-                         process_group=group, n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
-                         scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
-                         cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0),
-                         bucket_levels=buckets, fuse_table_adam=not args.separate_adam)
+        return make_chest_engine(device, precision, args.lr, group, args.seed,
+                                 n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
+                                 scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
+                                 cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
+                                           | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0),
+                                 bucket_levels=buckets, fuse_table_adam=not args.separate_adam)
 
     engine = make_engine(args.precision, pg)
     allreduce_bytes = engine.grad_flat.numel() * 4
@@ -299,7 +391,7 @@ def main():
         # (a) the YAML's own step: 1 024 rays of ONE projection, the reference's chunk-sum loss (train.py:69,127)
         m = CHEST["yaml_rays"]
         r1 = torch.empty(m, 8, device=device)
-        w1 = chunk_mean_weights(torch.ones(m, dtype=torch.bool, device=device), 200, "chunk_sum")
+        w1, _ = step_weights(m, device)
         dt = timed(lambda i: step(i, engine, m, r1, w1), 200, 20)
         sub_records = {"yaml_step_1024_rays": {"rays_per_step": m, "precision": args.precision, "ms_per_step": round(dt * 1e3, 4),
                                                "rays_per_s": m / dt, "loss": "chunk_sum (sum of 200-ray chunk means)"}}

@@ -189,6 +189,14 @@ typedef struct naf_render_cfg {
                                          level at a time chip-wide -- same results, the cache behaviour of a kernel that
                                          gathers every level of a tile (what a single fused gather+MLP kernel would see) */
 
+#define NAF_CFG_FORWARD_FUSED 8u      /* forward-only entry points (naf_render_forward, _forward_samples, naf_field_forward, _grid):
+                                         gathers + MLP + line integral in ONE kernel where the shape allows it (16 levels x 2
+                                         channels, bf16 MLP operands); the [L, B, C] features then never reach HBM and the calls
+                                         need no workspace (naf_forward_workspace_bytes).  Bit-identical to the two-kernel path. */
+#define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
+                                         (rounds 1-2) instead of one 16-byte window (same results; A/B timing only)      */
+#define NAF_CFG_FUSED_STORE_FEATURES 16u /* diagnostics: the fused kernel also stores the features it computed              */
+
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */
 int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host);
@@ -199,6 +207,12 @@ int naf_scatter_overflow_levels(const naf_render_cfg *cfg, uint64_t n_points, co
 /* Workspace size in bytes for naf_render_* / naf_field_forward over `n_points` points (= n_rays * n_samples for the
  * render entry points): feature and feature-gradient tensors [L, n_points, C] plus the MLP-gradient slabs. */
 size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points);
+
+/* Workspace size in bytes for the FORWARD-ONLY entry points (naf_render_forward, naf_render_forward_samples,
+ * naf_field_forward, naf_field_forward_grid) over `n_points` points: the [L, n_points, C] feature tensor and nothing else --
+ * 64 B per point in bf16 mode, 128 B in fp32 mode, against ~1.1 KB per point of the training layout -- or 256 bytes when
+ * NAF_CFG_FORWARD_FUSED applies.  A workspace of naf_render_workspace_bytes() is always large enough as well. */
+size_t naf_forward_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points);
 
 /* Forward only (eval, train.py:235-239): acc[r] = sum_s sigma(pts[r,s]) * dist[r,s]. */
 int naf_render_forward(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets,
@@ -259,10 +273,12 @@ int naf_field_forward(const float *pts, const void *embeddings, const int32_t *o
  * of tigre.py:388-400): axis k holds dims[k] values numpy.linspace(start[k], stop[k], dims[k]) (float64, cast to float32
  * like the dataset does), sigma is [dims[0], dims[1], dims[2]] in 'ij' order.  Bit-identical to naf_field_forward on the
  * materialised grid; the kernel walks the grid with axis 0 fastest, which turns most gathers of the hashed levels into L1
- * hits.  start / stop / dims are HOST arrays of three; the grid must lie inside [-bound, bound]. */
+ * hits.  start / stop / dims are HOST arrays of three; the grid must lie inside [-bound, bound].
+ * `workspace_bytes` is the size of `workspace`: the grid is evaluated in as many ranges of its traversal as that buffer needs
+ * (at least naf_forward_workspace_bytes(cfg, 1024); same bits for every split), so a 1024^3 query (foot_50) runs in any budget. */
 int naf_field_forward_grid(const double *start, const double *stop, const uint32_t *dims, const void *embeddings,
                            const int32_t *offsets, const float *mlp, float *sigma, const naf_render_cfg *cfg, void *workspace,
-                           void *stream);
+                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * T4  Adam (torch.optim.Adam semantics, trainer.py:54: lr, betas=(0.9,0.999), eps=1e-8, no weight decay,

@@ -20,6 +20,9 @@ SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED = 0, 1, 2
 CFG_PER_LEVEL_LAUNCHES = 1
 CFG_EXPLICIT_DEPTHS = 2
 CFG_LEVELS_INTERLEAVED = 4
+CFG_FORWARD_FUSED = 8
+CFG_FUSED_STORE_FEATURES = 16
+CFG_ENCODE_TWO_GATHERS = 32
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -88,6 +91,7 @@ SIGNATURES = {
     "naf_scatter_overflow_count": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32)]),
     "naf_scatter_overflow_levels": (_i32, [ctypes.POINTER(RenderCfg), _u64, _vp, ctypes.POINTER(ctypes.c_uint32 * 32)]),
     "naf_render_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
+    "naf_forward_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(RenderCfg), _u64]),
     "naf_render_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_forward_samples": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_render_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _i32, _vp]),
@@ -98,7 +102,8 @@ SIGNATURES = {
                                      ctypes.POINTER(TableAdam), _vp]),
     "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
     "naf_field_forward_grid": (_i32, [ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(ctypes.c_double * 3),
-                                      ctypes.POINTER(ctypes.c_uint32 * 3), _vp, _vp, _vp, _vp, ctypes.POINTER(RenderCfg), _vp, _vp]),
+                                      ctypes.POINTER(ctypes.c_uint32 * 3), _vp, _vp, _vp, _vp, ctypes.POINTER(RenderCfg), _vp,
+                                      ctypes.c_size_t, _vp]),
     "naf_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _u64, _f32, _f32, _f32, _f32, _u32, _f32, _i32, _vp]),
     "naf_normalize_inputs": (_i32, [_vp, _u64, _f32, _vp, _vp, _vp]),
 }

@@ -87,4 +87,4 @@ extern "C" int naf_profile_collect(char *buf, size_t buflen) {
 }
 
 extern "C" const char *naf_last_error(void) { return naf::g_last_error; }
-extern "C" int naf_abi_version(void) { return 2; }
+extern "C" int naf_abi_version(void) { return 3; }

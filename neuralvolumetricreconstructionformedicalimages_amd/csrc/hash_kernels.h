@@ -63,8 +63,10 @@ struct SrcGrid {
     double start[3], step[3], stop[3];
     uint32_t n[3];
     float bound;
+    uint32_t first;                    // a launch covers the points [first, first + B) of the traversal (chunked queries)
     // internal point index -> grid indices (axis 0 fastest, then 2, then 1)
     __device__ __forceinline__ void index(uint32_t b, uint32_t (&i)[3]) const {
+        b += first;
         i[0] = b % n[0];
         const uint32_t rest = b / n[0];
         i[2] = rest % n[2];
@@ -136,7 +138,10 @@ struct SrcRays {
         split(b, r, s);
         const float4 *ray = reinterpret_cast<const float4 *>(rays + (size_t)r * 8);
         const float4 a = ray[0], c = ray[1];                       // o.xyz d.x | d.yz near far
-        const float z = depth(r, s, c.z, c.w);
+        position(a, c, depth(r, s, c.z, c.w), out);
+    }
+    // the point at depth z on the ray record (a, c): o + d z, clamped, normalised to [0, 1]
+    __device__ __forceinline__ void position(const float4 &a, const float4 &c, float z, float (&out)[3]) const {
         const float lim = bound - 1e-6f, denom = 2.0f * bound;
         const float o[3] = {a.x, a.y, a.z}, dir[3] = {a.w, c.x, c.y};
 #pragma unroll

@@ -284,6 +284,65 @@ __device__ __forceinline__ void raw_unpack(const RawVec<T, C> &r, float (&v)[C])
     for (uint32_t c = 0; c < C; ++c) v[c] = Conv<T>::load(&e[c]);
 }
 
+// ---- x-neighbour corner pairs through one 16-byte window ------------------------------------------------------------------
+// The corners (x, x+1) of a cell sit in rows r and r' with r ^ r' = x ^ (x+1) = 1, 3, 7, ... on hashed levels (the prime of
+// dimension 0 is 1, hashencoder.cu:36-52) and r' = r + 1 on dense ones: 83 % of the pairs are less than four rows apart.  The
+// texture path of a CU (TCP) spends one tag lookup per lane and instruction whatever the access width (counter evidence:
+// profiles/round3_encode_cache_counters.md: encode_kernel sits at ~0.9 TCP accesses per clock and CU with L2 at 40 % of its
+// bandwidth), so ONE 4-byte-aligned dwordx4 at min(r, r') replaces two dword gathers for those pairs; the far row of the rest
+// comes from a second, exec-masked load.  Same rows, same values, same arithmetic afterwards -- only fewer L1 accesses.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename T, uint32_t C>
+struct PairWindow {
+    static constexpr uint32_t kRowBytes = C * (uint32_t)sizeof(typename T::store_t);
+    static constexpr bool kUsable = kRowBytes == 4u || kRowBytes == 8u;
+    static constexpr uint32_t kDw = kUsable ? kRowBytes / 4u : 1u;       // dwords per row
+    static constexpr uint32_t kWin = 4u / kDw;                            // rows per window
+    u32x4_a4 win;
+    uint32_t far[kDw];
+    uint32_t d, lo_off;                // window index of the higher / lower row
+    bool swap;                         // the first corner is the higher row
+
+    // `safe_last`: the last row of this level at which a window still ends inside the table (>= the level's size for every
+    // level but the last, so the clamp only ever moves windows at the very end of the allocation)
+    __device__ __forceinline__ void issue(const typename T::store_t *__restrict__ grid, uint32_t ra, uint32_t rb, uint32_t safe_last) {
+        const uint32_t lo = min(ra, rb), hi = max(ra, rb), base = min(lo, safe_last);
+        swap = ra > rb;
+        d = hi - base;
+        lo_off = lo - base;
+        const uint32_t *words = reinterpret_cast<const uint32_t *>(grid);
+        win = *reinterpret_cast<const u32x4_a4 *>(words + (size_t)base * kDw);
+#pragma unroll
+        for (uint32_t i = 0; i < kDw; ++i) far[i] = 0u;
+        if (d >= kWin) {
+#pragma unroll
+            for (uint32_t i = 0; i < kDw; ++i) far[i] = words[(size_t)hi * kDw + i];
+        }
+    }
+    __device__ __forceinline__ void row_at(uint32_t i, uint32_t (&out)[kDw]) const {
+        if constexpr (kDw == 1u) out[0] = i == 1u ? win.y : i == 2u ? win.z : i == 3u ? win.w : win.x;
+        else { out[0] = i == 1u ? win.z : win.x; out[1] = i == 1u ? win.w : win.y; }
+    }
+    // values of the first (a) and second (b) corner as fp32
+    __device__ __forceinline__ void finish(float (&a)[C], float (&b)[C]) const {
+        RawVec<T, C> lo, hi;
+#pragma unroll
+        for (uint32_t i = 0; i < kDw; ++i) lo.w[i] = i == 0u ? win.x : win.y;
+        if (lo_off != 0u) row_at(lo_off, lo.w);                            // only within kWin rows of the end of the table
+        if (d < kWin) row_at(d, hi.w);
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < kDw; ++i) hi.w[i] = far[i];
+        }
+        RawVec<T, C> ra, rb;
+#pragma unroll
+        for (uint32_t i = 0; i < kDw; ++i) { ra.w[i] = swap ? hi.w[i] : lo.w[i]; rb.w[i] = swap ? lo.w[i] : hi.w[i]; }
+        raw_unpack<T, C>(ra, a);
+        raw_unpack<T, C>(rb, b);
+    }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, i.e.
 // s_waitcnt vmcnt(0): every wave would sit out the round trip of the global stores it has just issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -22,6 +22,7 @@
 #include "hash_kernels.h"
 #include "field_mlp.h"
 #include "field_mlp16.h"
+#include "fused_forward.h"
 #include "scatter_binned.h"
 
 namespace naf {
@@ -142,8 +143,10 @@ __device__ __forceinline__ float emit_samples(float term, float sigma, float car
 // grid point p in the caller's [n0, n1, n2] array.
 struct OutMap {
     uint32_t n0, n1, n2;          // n0 == 0: identity
+    uint32_t first;               // grid queries in chunks: point p of the launch is point first + p of the traversal
     __device__ __forceinline__ size_t at(uint32_t p) const {
         if (n0 == 0u) return p;
+        p += first;
         const uint32_t i0 = p % n0, rest = p / n0, i2 = rest % n2, i1 = rest / n2;
         return ((size_t)i0 * n1 + i1) * n2 + i2;
     }
@@ -264,6 +267,72 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             Feat16Raw raw;
             load_feat16(feat, B, p, g, raw);
             const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(raw), a);
+            if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
+        }
+    }
+}
+
+// ---- 2c: gathers + MLP + line integral in one kernel, features in registers (fused_forward.h; forward-only calls) -----------
+// Src = SrcRays: one wave per ray (out[r] = sum_s sigma * dist, optional per-sample outputs).  Any other source: a plain point
+// list / generated grid, out[omap.at(p)] = sigma(p).  `feat` != nullptr additionally stores the features (diagnostic:
+// NAF_CFG_FUSED_STORE_FEATURES times what the feature traffic itself costs this kernel).
+template <typename TT, typename Src>
+__global__ void __launch_bounds__(256, 3)
+fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
+                     const float *__restrict__ mlp, float *__restrict__ out, float *__restrict__ sigma_out,
+                     float *__restrict__ depth_out, uint16_t *__restrict__ feat, uint32_t n_items, uint32_t B, uint32_t H, int act,
+                     OutMap omap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t kShAligned = (Mlp16Shared::kBytes + 15u) & ~15u;
+    LevelRec *recs = reinterpret_cast<LevelRec *>(smem + kShAligned);
+    build_level_recs(recs, offsets, kFusedLevels, H);
+    Mlp16Shared::build(smem, mlp, 4);                          // ends with a workgroup barrier: the level records are visible too
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t table_rows = (uint32_t)offsets[kFusedLevels];
+    Act16 a;
+    if constexpr (std::is_same<Src, SrcRays>::value) {
+        const uint32_t S = src.S, tiles = (S + 15u) / 16u;
+        const bool use_zbuf = S <= kMaxSamplesLds;
+        float *zbuf = reinterpret_cast<float *>(smem + kShAligned + kFusedLevels * (uint32_t)sizeof(LevelRec)) + (threadIdx.x >> 6) * kMaxSamplesLds;
+        for (uint32_t r = wave; r < n_items; r += n_waves) {
+            const float4 *ray = reinterpret_cast<const float4 *>(src.rays + (size_t)r * 8);
+            const float4 ra = ray[0], rc = ray[1];
+            const float near = rc.z, far = rc.w;
+            const float dnorm = sqrtf(ra.w * ra.w + rc.x * rc.x + rc.y * rc.y);
+            if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
+            float part = 0.0f, carry = 0.0f;
+            for (uint32_t k = 0; k < tiles; ++k) {
+                const uint32_t s = 16u * k + c;
+                const bool valid = s < S;
+                const uint32_t sc = valid ? s : S - 1u;
+                float x[3];
+                src.position(ra, rc, use_zbuf ? zbuf[sc] : src.depth(r, sc, near, far), x);
+                const Feat16Raw f = gather_point_features<TT>(recs, g, x, table, table_rows);
+                if (feat != nullptr && valid) store_point_features(feat, B, r * S + s, g, f);
+                const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(f), a);
+                const float sigma = last_act(act, z4);
+                const float term = !valid ? 0.0f
+                                 : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                if (sigma_out != nullptr || depth_out != nullptr)          // per-sample outputs (wave-uniform test)
+                    carry = emit_samples<16>(term, sigma, carry, valid && g == 0u, c, sigma_out, depth_out, (size_t)r * S + s);
+                if (g == 0u) part += term;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);     // the 16 points of lane group 0
+            if (lane == 0) out[r] = part;
+        }
+    } else {
+        const uint32_t tiles = (n_items + 15u) / 16u;
+        for (uint32_t k = wave; k < tiles; k += n_waves) {
+            const uint32_t p0 = 16u * k + c;
+            const bool valid = p0 < n_items;
+            const uint32_t p = valid ? p0 : n_items - 1u;
+            float x[3];
+            src.get(p, x);
+            const Feat16Raw f = gather_point_features<TT>(recs, g, x, table, table_rows);
+            if (feat != nullptr && valid) store_point_features(feat, B, p, g, f);
+            const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(f), a);
             if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
         }
     }
@@ -851,7 +920,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -863,10 +932,10 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
 // features are produced by a converting instantiation below.
 __host__ __device__ constexpr uint32_t encode_points_per_thread(uint32_t C) { return C <= 2 ? 4u : C == 4 ? 2u : 1u; }
 
-template <typename TT, typename FT, uint32_t C, typename Src>
+template <typename TT, typename FT, uint32_t C, typename Src, bool kWindow>
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, bool interleaved) {
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, bool interleaved, uint32_t n_levels) {
     // level-major by default: blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and that level's
     // slice of the table stays in the L2s.  `interleaved` (NAF_CFG_LEVELS_INTERLEAVED, a diagnostic) puts the level in x instead:
     // every XCD then walks all levels at once -- the cache behaviour of a kernel that gathers all levels of a point tile.
@@ -876,10 +945,49 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
+    const uint32_t stride = grid_x * blockDim.x;
+    if constexpr (kWindow) {
+        // x-neighbour corners through one 16-byte window each (PairWindow, naf_device.h): 4.7 instead of 8 L1 accesses per point
+        using PW = PairWindow<TT, C>;
+        constexpr uint32_t kPts = 2u;                            // 8 windows + their far rows in flight per lane
+        const uint32_t safe_last = (uint32_t)offsets[n_levels] - PW::kWin - m.offset;
+        for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
+            float w[kPts][8];
+            PW pw[kPts][4];
+#pragma unroll
+            for (uint32_t k = 0; k < kPts; ++k) {
+                const uint32_t b = min(b0 + k * stride, B - 1u);
+                float x[3], frac[3];
+                uint32_t pg[3];
+                src.get(b, x);
+                locate<3>(x, m.scale, frac, pg);
+                uint32_t row[8];
+                cell_corners<MODE, 3>(m, frac, pg, w[k], row);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) pw[k][j].issue(grid, row[2 * j], row[2 * j + 1], safe_last);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kPts; ++k) {
+                const uint32_t b = b0 + k * stride;
+                float a[C];
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ++ch) a[ch] = 0.0f;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    float va[C], vb[C];
+                    pw[k][j].finish(va, vb);
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][2 * j], va[ch], a[ch]);
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][2 * j + 1], vb[ch], a[ch]);
+                }
+                if (b < B) store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
+            }
+        }
+    } else {
     // several points per thread and iteration: 32 independent gathers in flight per lane (measured on the chest step,
     // C = 2: 1 / 2 / 4 / 8 points -> 3.28 / 2.99 / 2.81 / 2.90 ms)
     constexpr uint32_t kPts = encode_points_per_thread(C);
-    const uint32_t stride = grid_x * blockDim.x;
     for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
         float w[kPts][8], v[kPts][8][C];
 #pragma unroll
@@ -907,26 +1015,31 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
             if (b < B) store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
         }
     }
+    }
     });
 }
 
 template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
     using FT = typename P::feat_t;
-    constexpr uint32_t kPts = encode_points_per_thread(C);
+    constexpr bool kCanWindow = PairWindow<TT, C>::kUsable;
+    const bool window = kCanWindow && (cfg->flags & NAF_CFG_ENCODE_TWO_GATHERS) == 0u;
+    auto kern = encode_kernel<TT, FT, C, Src, false>;
+    if constexpr (kCanWindow) { if (window) kern = encode_kernel<TT, FT, C, Src, true>; }
+    const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
         for (uint32_t l = 0; l < cfg->L; ++l) {
             ProfScope prof_(level_name(names, l), s);
-            hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, false);
+            hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, false, cfg->L);
         }
         return check_launch("encode_kernel");
     }
     const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
     const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
-    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL((encode_kernel<TT, FT, C, Src>), interleaved ? dim3(cfg->L, gx) : dim3(gx, cfg->L), dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, interleaved); }
+    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, interleaved ? dim3(cfg->L, gx) : dim3(gx, cfg->L), dim3(256), 0, s, src,
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, interleaved, cfg->L); }
     return check_launch("encode_kernel");
 }
 
@@ -942,7 +1055,7 @@ static int dispatch_encode(const Src &src, const void *table, const int32_t *off
 template <typename P, uint32_t C, bool kRays>
 static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &src, float *out, uint32_t n_items, uint32_t B,
                            const naf_render_cfg *cfg, hipStream_t s, float *sigma_out = nullptr, float *depth_out = nullptr,
-                           OutMap omap = OutMap{0u, 0u, 0u}) {
+                           OutMap omap = OutMap{0u, 0u, 0u, 0u}) {
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
         {
             const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u;
@@ -1134,22 +1247,60 @@ static SrcRays make_src(const float *rays, const float *t_rand, const naf_render
     return s;
 }
 
+// ---- forward-only calls ----------------------------------------------------------------------------------------------
+// They need the [L, n_points, C] features and nothing else of the training workspace -- or, where the single fused kernel
+// applies (NAF_CFG_FORWARD_FUSED, the canonical field in bf16 mode), no workspace at all.
+static bool forward_fused(const naf_render_cfg *cfg) {
+    return (cfg->flags & NAF_CFG_FORWARD_FUSED) != 0u && cfg->mlp_precision == NAF_BF16 && cfg->C == 2u && cfg->L == kFusedLevels;
+}
+static size_t feature_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
+    const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
+    return ((size_t)n_points * cfg->L * cfg->C * esz + 255) & ~(size_t)255;
+}
+static size_t forward_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
+    if (forward_fused(cfg) && (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) == 0u) return 256;
+    return feature_bytes(cfg, n_points) + 256;
+}
+
+template <typename TT, typename Src>
+static int launch_fused_forward(const Src &src, const void *table, const int32_t *offsets, const float *mlp, float *out, float *sigma_out,
+                                float *depth_out, void *feat, uint32_t n_items, uint32_t B, const naf_render_cfg *cfg, OutMap omap, hipStream_t s) {
+    constexpr bool kRays = std::is_same<Src, SrcRays>::value;
+    const uint32_t lds = ((Mlp16Shared::kBytes + 15u) & ~15u) + kFusedLevels * (uint32_t)sizeof(LevelRec) + (kRays ? 4u * kMaxSamplesLds * 4u : 0u);
+    const uint64_t waves = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves + 3) / 4, 256u * 8u));
+    uint16_t *fout = (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) != 0u ? (uint16_t *)feat : nullptr;
+    { ProfScope prof_("fused_forward_kernel", s); hipLaunchKernelGGL((fused_forward_kernel<TT, Src>), dim3(grid), dim3(256), lds, s, src,
+                       (const typename TT::store_t *)table, offsets, mlp, out, sigma_out, depth_out, fout, n_items, B, cfg->H, cfg->last_activation, omap); }
+    return check_launch("fused_forward_kernel");
+}
+template <typename Src>
+static int run_fused_forward(const Src &src, const void *table, const int32_t *offsets, const float *mlp, float *out, float *sigma_out,
+                             float *depth_out, void *feat, uint32_t n_items, uint32_t B, const naf_render_cfg *cfg, OutMap omap, hipStream_t s) {
+    switch (cfg->table_dtype) {
+        case NAF_F32: return launch_fused_forward<F32>(src, table, offsets, mlp, out, sigma_out, depth_out, feat, n_items, B, cfg, omap, s);
+        case NAF_F16: return launch_fused_forward<F16>(src, table, offsets, mlp, out, sigma_out, depth_out, feat, n_items, B, cfg, omap, s);
+        default: return launch_fused_forward<BF16>(src, table, offsets, mlp, out, sigma_out, depth_out, feat, n_items, B, cfg, omap, s);
+    }
+}
+
 template <typename P, uint32_t C>
 static int render_forward_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, const float *mlp,
                                float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s,
-                               float *sigma_out = nullptr, float *depth_out = nullptr) {
+                               float *sigma_out = nullptr, float *depth_out = nullptr, bool keep_features = false) {
     const uint32_t B = n_rays * cfg->n_samples;
-    const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
-    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    return run_mlp_forward<P, C, true>(w.feat, mlp, src, acc, n_rays, B, cfg, s, sigma_out, depth_out);
+    if (forward_fused(cfg) && !keep_features)              // a training step needs the features for its backward pass
+        return run_fused_forward(src, emb, offsets, mlp, acc, sigma_out, depth_out, ws, n_rays, B, cfg, OutMap{0u, 0u, 0u, 0u}, s);
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s)) return rc;        // the features sit at the workspace base
+    return run_mlp_forward<P, C, true>(ws, mlp, src, acc, n_rays, B, cfg, s, sigma_out, depth_out);
 }
 
 template <typename P, uint32_t C>
 static int render_backward_impl(const float *rays, const float *t_rand, const float *grad_acc, const void *emb, const int32_t *offsets,
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
                                 void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
-                                const AdamTail *adam = nullptr) {
+                                const AdamTail *adam = nullptr, bool from_train = false) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
@@ -1159,7 +1310,8 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
         tail.overflow = w.overflow;
         adam = &tail;
     }
-    if (!features_valid)
+    // (a fused forward of the same cfg left no features behind unless it was asked to store them)
+    if (!features_valid || (forward_fused(cfg) && (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) == 0u && !from_train))
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
     if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, n_rays, B, cfg, s)) return rc;
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
@@ -1173,7 +1325,7 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
                              const AdamTail *adam = nullptr) {
-    if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s)) return rc;
+    if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true)) return rc;
     const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
     {   // the partial sums live behind grad_acc in the workspace (carve reserves 256 bytes for them)
         float *partial = w.grad_acc + (((size_t)n_rays + 63) & ~(size_t)63);
@@ -1183,26 +1335,27 @@ static int render_train_impl(const float *rays, const float *t_rand, const float
         if (blocks > 1u && loss_out != nullptr) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, blocks, loss_out);
     }
     if (int rc = check_launch("loss_grad_kernel")) return rc;
-    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam);
+    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true);
 }
 
 template <typename P, uint32_t C>
 static int field_forward_impl(const float *pts, const void *emb, const int32_t *offsets, const float *mlp, float *sigma, uint32_t B,
                               const naf_render_cfg *cfg, void *ws, hipStream_t s) {
-    const Workspace w = carve(ws, cfg, B);
     SrcRaw src{pts, cfg->bound};
-    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    if (forward_fused(cfg)) return run_fused_forward(src, emb, offsets, mlp, sigma, nullptr, nullptr, ws, B, B, cfg, OutMap{0u, 0u, 0u, 0u}, s);
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s)) return rc;
     SrcRays none{};
-    return run_mlp_forward<P, C, false>(w.feat, mlp, none, sigma, B, B, cfg, s);
+    return run_mlp_forward<P, C, false>(ws, mlp, none, sigma, B, B, cfg, s);
 }
 
 template <typename P, uint32_t C>
 static int field_forward_grid_impl(const SrcGrid &src, const void *emb, const int32_t *offsets, const float *mlp, float *sigma, uint32_t B,
                                    const naf_render_cfg *cfg, void *ws, hipStream_t s) {
-    const Workspace w = carve(ws, cfg, B);
-    if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
+    const OutMap omap{src.n[0], src.n[1], src.n[2], src.first};
+    if (forward_fused(cfg)) return run_fused_forward(src, emb, offsets, mlp, sigma, nullptr, nullptr, ws, B, B, cfg, omap, s);
+    if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s)) return rc;
     SrcRays none{};
-    return run_mlp_forward<P, C, false>(w.feat, mlp, none, sigma, B, B, cfg, s, nullptr, nullptr, OutMap{src.n[0], src.n[1], src.n[2]});
+    return run_mlp_forward<P, C, false>(ws, mlp, none, sigma, B, B, cfg, s, nullptr, nullptr, omap);
 }
 
 #define NAF_DISPATCH_PC(FN, ...)                                                                      \
@@ -1248,6 +1401,11 @@ extern "C" int naf_scatter_overflow_levels(const naf_render_cfg *cfg, uint64_t n
 extern "C" size_t naf_render_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
     if (!cfg) return 0;
     return carve(nullptr, cfg, n_points).bytes;
+}
+
+extern "C" size_t naf_forward_workspace_bytes(const naf_render_cfg *cfg, uint64_t n_points) {
+    if (!cfg) return 0;
+    return forward_workspace_bytes(cfg, n_points);
 }
 
 static int check_points(uint64_t n_points) {
@@ -1396,7 +1554,7 @@ extern "C" int naf_field_forward(const float *pts, const void *embeddings, const
 
 extern "C" int naf_field_forward_grid(const double *start, const double *stop, const uint32_t *dims, const void *embeddings,
                                       const int32_t *offsets, const float *mlp, float *sigma, const naf_render_cfg *cfg,
-                                      void *workspace, void *stream) {
+                                      void *workspace, size_t workspace_bytes, void *stream) {
     if (int rc = check_cfg(cfg, "field_forward_grid")) return rc;
     if (!start || !stop || !dims || !embeddings || !offsets || !mlp || !sigma || !workspace)
         return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward_grid: null pointer");
@@ -1415,6 +1573,19 @@ extern "C" int naf_field_forward_grid(const double *start, const double *stop, c
         if (int rc = check_points(total)) return rc;
     }
     src.bound = cfg->bound;
-    const uint32_t B = (uint32_t)total;
-    NAF_DISPATCH_PC(field_forward_grid_impl, src, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream);
+    // The grid is walked in ranges of its traversal order that fit the caller's workspace (every point is evaluated on its own,
+    // so the ranges give the same bits as one call): a 1024^3 query needs 64 GiB of features at once, or any smaller buffer.
+    const size_t per_point = forward_workspace_bytes(cfg, 1u << 20) > 256 ? (size_t)cfg->L * cfg->C * (cfg->mlp_precision == NAF_F32 ? 4u : 2u) : 0u;
+    uint64_t chunk = total;
+    if (per_point != 0u) {
+        if (workspace_bytes < 512u + 1024u * per_point) return fail(NAF_ERR_INVALID_ARGUMENT, "field_forward_grid: workspace too small (see naf_forward_workspace_bytes)");
+        chunk = std::min<uint64_t>(total, ((workspace_bytes - 512u) / per_point) & ~(uint64_t)1023u);
+    }
+    for (uint64_t first = 0; first < total; first += chunk) {
+        src.first = (uint32_t)first;
+        const uint32_t B = (uint32_t)std::min<uint64_t>(chunk, total - first);
+        const int rc = [&]() -> int { NAF_DISPATCH_PC(field_forward_grid_impl, src, embeddings, offsets, mlp, sigma, B, cfg, workspace, (hipStream_t)stream); }();
+        if (rc != NAF_OK) return rc;
+    }
+    return NAF_OK;
 }

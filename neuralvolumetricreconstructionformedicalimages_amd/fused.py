@@ -26,6 +26,9 @@ def _bump(device):
 
 _default_scatter_mode = _abi.SCATTER_AUTO
 _default_flags = 0
+# forward-only calls (projection render, volume query) run gathers + MLP in one kernel where the shape allows it; set False to
+# take the two-kernel path (same bits)
+forward_fused = True
 
 
 @contextlib.contextmanager
@@ -46,8 +49,10 @@ def scatter_mode(mode, flags=None):
         _default_scatter_mode, _default_flags = saved
 
 
-def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_base=0, scatter=None, flags=None):
+def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_base=0, scatter=None, flags=None, forward_only=False):
     enc = net.encoder
+    if flags is None:
+        flags = _default_flags | (_abi.CFG_FORWARD_FUSED if (forward_only and forward_fused) else 0)
     table_dtype = _abi.dtype_code(enc.embeddings.dtype)
     if mlp_precision is None:          # parity mode for fp32 tables, bf16 matrix cores for 16-bit tables
         mlp_precision = _abi.F32 if table_dtype == _abi.F32 else _abi.BF16
@@ -56,17 +61,42 @@ def render_cfg(net, n_samples, perturb, mlp_precision=None, seed=0, ray_index_ba
                           mlp_precision=int(mlp_precision), last_activation=LAST_ACTIVATIONS[net.last_activation],
                           seed=int(seed) & (2 ** 64 - 1), ray_index_base=int(ray_index_base), log2_hashmap_size=int(enc.log2_hashmap_size),
                           scatter_mode=_default_scatter_mode if scatter is None else int(scatter),
-                          flags=_default_flags if flags is None else int(flags))
+                          flags=int(flags))
 
 
 def workspace(cfg, n_points, device):
-    """Grow-only scratch buffer per device (features, feature gradients, MLP-gradient slabs)."""
-    need = int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), int(n_points)))
+    """Grow-only scratch buffer per device for calls that run a backward pass (features, feature gradients, MLP-gradient slabs,
+    scatter records: ~1.1 KB per point)."""
+    return _grow(device, int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), int(n_points))))
+
+
+# Forward-only calls need the [L, n, C] features and nothing else (64 B per point in bf16 mode, 128 B in fp32 mode; nothing with
+# the fused kernel).  Their workspace is capped: a volume query walks its grid in as many ranges as the cap requires
+# (`naf_field_forward_grid` does that itself, bit-identically), so the 1024^3 query of foot_50 runs in the same 1 GiB as the
+# 256^3 one of chest_50 (train.py:246-250; the training layout would want 196 GiB for it).
+FORWARD_WORKSPACE_CAP = 1 << 30
+
+
+def forward_workspace(cfg, n_points, device, cap=None):
+    need = int(_abi.lib().naf_forward_workspace_bytes(ctypes.byref(cfg), int(n_points)))
+    floor = int(_abi.lib().naf_forward_workspace_bytes(ctypes.byref(cfg), 1024)) + 512
+    return _grow(device, max(floor, min(need, FORWARD_WORKSPACE_CAP if cap is None else int(cap))))
+
+
+def _grow(device, need):
     buf = _workspaces.get(device)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=device)
         _workspaces[device] = buf
     return buf
+
+
+def forward_points_per_call(cfg, device, cap=None):
+    """Points one forward-only call may cover under the workspace cap (callers split larger point lists / ray batches)."""
+    per_point = int(_abi.lib().naf_forward_workspace_bytes(ctypes.byref(cfg), 1 << 20)) / float(1 << 20)
+    if per_point < 1.0:                                   # fused kernel: no features in HBM
+        return (1 << 31) - 1
+    return max(1024, int(((FORWARD_WORKSPACE_CAP if cap is None else int(cap)) - 512) / per_point) // 1024 * 1024)
 
 
 def _offsets(enc, device):
@@ -122,6 +152,29 @@ def fused_render(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_precisi
         if z_vals.shape != (rays.shape[0], n_samples):
             raise ValueError("z_vals must be [n_rays, n_samples]")
         t_rand, perturb, flags = z_vals, False, _default_flags | _abi.CFG_EXPLICIT_DEPTHS
+    needs_grad = torch.is_grad_enabled() and (net.encoder.embeddings.requires_grad or any(p.requires_grad for p in net.layers.parameters()))
+    if not needs_grad:
+        # eval (train.py:235-239 under torch.no_grad()): forward-only call -- the features are not kept, so the single fused
+        # kernel applies and the workspace is the features alone (or nothing)
+        if flags is not None and forward_fused:
+            flags |= _abi.CFG_FORWARD_FUSED
+        cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed, flags=flags, forward_only=True)
+        rays = rays.contiguous().float()
+        n = rays.shape[0]
+        acc = torch.empty(n, device=rays.device, dtype=torch.float32)
+        step = max(1, forward_points_per_call(cfg, rays.device) // int(n_samples))
+        ws = forward_workspace(cfg, min(n, step) * int(n_samples), rays.device)
+        enc = net.encoder
+        emb, mlp, offs = enc.embeddings.detach().contiguous(), net.packed_mlp().detach().contiguous(), _offsets(enc, rays.device)
+        for b in range(0, n, step):                      # rays are independent; the jitter stream is per global ray index
+            m = min(step, n - b)
+            cfg.ray_index_base = b
+            tr = None if t_rand is None else t_rand[b:b + m]
+            _abi.check(_abi.lib().naf_render_forward(_abi.ptr(rays[b:b + m]), _abi.ptr(tr), _abi.ptr(emb), _abi.ptr(offs), _abi.ptr(mlp),
+                                                     _abi.ptr(acc[b:b + m]), m, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()),
+                       "render_forward")
+        _bump(rays.device)
+        return acc
     cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed, flags=flags)
     return _FusedRender.apply(rays, t_rand, net.encoder.embeddings, net.packed_mlp(), _offsets(net.encoder, rays.device), cfg)
 
@@ -150,8 +203,8 @@ def render_samples(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_preci
     sum_{s' <= s} sigma * dist (a wave prefix sum in the MLP kernel); its last column equals acc."""
     rays = rays.contiguous().float()
     n = rays.shape[0]
-    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed)
-    ws = workspace(cfg, n * cfg.n_samples, rays.device)
+    cfg = render_cfg(net, n_samples, perturb, mlp_precision, seed, forward_only=True)
+    ws = forward_workspace(cfg, n * cfg.n_samples, rays.device, cap=1 << 62)
     acc = torch.empty(n, device=rays.device, dtype=torch.float32)
     sigma = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_sigma else None
     depth = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_depth else None
@@ -165,23 +218,24 @@ def render_samples(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_preci
 
 
 @torch.no_grad()
-def field_query_grid(net, starts, stops, dims, mlp_precision=None):
+def field_query_grid(net, starts, stops, dims, mlp_precision=None, workspace_cap=None):
     """sigma on the regular grid whose axis k is numpy.linspace(starts[k], stops[k], dims[k]) -> [d0, d1, d2]
     (`naf_field_forward_grid`): the volume query of train.py:246-250 without materialising the [n^3, 3] point list, bit-identical
-    to `field_query` on it and faster (the kernel walks the grid along x)."""
+    to `field_query` on it and faster (the kernel walks the grid along x).  The library evaluates the grid in as many ranges
+    as the forward workspace (`workspace_cap` bytes, default FORWARD_WORKSPACE_CAP) requires -- same values for any cap."""
     enc = net.encoder
     device = enc.embeddings.device
     dims = [int(v) for v in dims]
     B = dims[0] * dims[1] * dims[2]
     if max(abs(float(v)) for v in list(starts) + list(stops)) > net.bound:
         raise ValueError(f"HashGrid encoder: inputs range [{min(starts)}, {max(stops)}] not in [{-net.bound}, {net.bound}]!")
-    cfg = render_cfg(net, 2, False, mlp_precision)
-    ws = workspace(cfg, B, device)
+    cfg = render_cfg(net, 2, False, mlp_precision, forward_only=True)
+    ws = forward_workspace(cfg, B, device, workspace_cap)
     sigma = torch.empty(dims, device=device, dtype=torch.float32)
     a, b, d = (ctypes.c_double * 3)(*[float(v) for v in starts]), (ctypes.c_double * 3)(*[float(v) for v in stops]), (ctypes.c_uint32 * 3)(*dims)
     _abi.check(_abi.lib().naf_field_forward_grid(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), _abi.ptr(enc.embeddings.detach().contiguous()),
                                                  _abi.ptr(_offsets(enc, device)), _abi.ptr(net.packed_mlp().contiguous()), _abi.ptr(sigma),
-                                                 ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "field_forward_grid")
+                                                 ctypes.byref(cfg), _abi.ptr(ws), ws.numel(), _abi.stream_ptr()), "field_forward_grid")
     _bump(device)
     return sigma
 
@@ -194,13 +248,16 @@ def field_query(net, pts, mlp_precision=None):
     B = flat.shape[0]
     if enc.strict_range:
         enc._normalize(flat, net.bound)          # raises ValueError like hashgrid.py:122-123
-    cfg = render_cfg(net, 2, False, mlp_precision)
-    ws = workspace(cfg, B, flat.device)
+    cfg = render_cfg(net, 2, False, mlp_precision, forward_only=True)
+    step = forward_points_per_call(cfg, flat.device)
+    ws = forward_workspace(cfg, min(B, step), flat.device)
     sigma = torch.empty(B, device=flat.device, dtype=torch.float32)
     mlp = net.packed_mlp().contiguous()
     emb = enc.embeddings.detach().contiguous()
-    _abi.check(_abi.lib().naf_field_forward(_abi.ptr(flat), _abi.ptr(emb), _abi.ptr(_offsets(enc, flat.device)), _abi.ptr(mlp),
-                                            _abi.ptr(sigma), B, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()),
-               "field_forward")
+    for b in range(0, B, step):                          # points are independent: the split changes nothing
+        n = min(step, B - b)
+        _abi.check(_abi.lib().naf_field_forward(_abi.ptr(flat[b:b + n]), _abi.ptr(emb), _abi.ptr(_offsets(enc, flat.device)), _abi.ptr(mlp),
+                                                _abi.ptr(sigma[b:b + n]), n, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()),
+                   "field_forward")
     _bump(flat.device)          # a pending _FusedRender.backward must recompute its features
     return sigma.reshape(list(pts.shape[:-1]) + [1])

@@ -116,7 +116,6 @@ class Trainer:
         self.train_dset = train_dset
         self.eval_dset = Dataset(data, cfg["train"]["n_rays"], "val", device) if self.i_eval > 0 else None
         self.train_dloader = torch.utils.data.DataLoader(train_dset, batch_size=cfg["train"]["n_batch"])
-        self.voxels = self.eval_dset.voxels if self.i_eval > 0 else None
 
         if backend.get("seed") is not None:                # optional: reproducible initialisation (the reference seeds nothing)
             torch.manual_seed(int(backend["seed"]))
@@ -168,6 +167,12 @@ class Trainer:
 
         self.writer = SummaryWriter(self.expdir) if (SummaryWriter is not None and self.rank == 0) else _NullWriter()
         self.writer.add_text("parameters", self.args2string(cfg), global_step=0)
+
+    @property
+    def voxels(self):
+        """The [n1, n2, n3, 3] voxel-centre list of trainer.py:41 -- built when somebody asks for it: the fused volume query
+        generates the grid inside the kernel (`field_query_grid`), and at foot_50's 1024^3 the list alone is 12.9 GB."""
+        return self.eval_dset.voxels if self.eval_dset is not None else None
 
     def args2string(self, hp):
         json_hp = json.dumps(hp, indent=2, default=str)

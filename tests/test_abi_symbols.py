@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_abi.SIGNATURES) == _declared()
-    assert _abi.lib().naf_abi_version() == 2
+    assert _abi.lib().naf_abi_version() == 3
     assert _abi.lib().naf_last_error() is not None
 
 
@@ -77,8 +77,21 @@ def test_argument_validation_needs_no_gpu():
     cfg.flags = 0
     dims = (ctypes.c_uint32 * 3)(0xffffffff, 0xffffffff, 0xffffffff)
     ends = (ctypes.c_double * 3)(-0.1, -0.1, -0.1), (ctypes.c_double * 3)(0.1, 0.1, 0.1)
-    assert lib.naf_field_forward_grid(ends[0], ends[1], dims, one, one, one, one, ctypes.byref(cfg), one, None) == -1
+    assert lib.naf_field_forward_grid(ends[0], ends[1], dims, one, one, one, one, ctypes.byref(cfg), one, 1 << 30, None) == -1
     assert b"2^31 points" in lib.naf_last_error()
+    # ... and one whose workspace cannot hold the features of even 1024 points is refused, not overrun
+    dims = (ctypes.c_uint32 * 3)(64, 64, 64)
+    assert lib.naf_field_forward_grid(ends[0], ends[1], dims, one, one, one, one, ctypes.byref(cfg), one, 4096, None) == -1
+    assert b"workspace too small" in lib.naf_last_error()
+    # forward-only calls ask for the features alone (a 1024^3 query wanted 196 GiB of TRAINING workspace): 64 B per
+    # point in bf16 mode, nothing with the fused kernel, and the front end caps what it allocates (the grid is walked in ranges)
+    from neuralvolumetricreconstructionformedicalimages_amd import fused
+    n = 1 << 30
+    assert lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n) == 64 * n + 256
+    assert lib.naf_render_workspace_bytes(ctypes.byref(cfg), n) > 3 * lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n)
+    cfg.flags = _abi.CFG_FORWARD_FUSED
+    assert lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n) == 256
+    assert fused.FORWARD_WORKSPACE_CAP <= 8 << 30
 
 
 def test_product_has_no_cpu_fallback():

@@ -1,0 +1,184 @@
+"""GPU tests of the forward-only paths added in round 3 (all through the C ABI, `-m gpu`):
+
+  * the single fused kernel (gathers + MLP + line integral, `NAF_CFG_FORWARD_FUSED`) against the two-kernel path: bit-identical
+    for ray batches (incl. per-sample outputs), point lists and generated grids, for bf16 / fp16 / fp32 tables;
+  * the encoder's x-neighbour window gathers (`PairWindow`) against the two-gather form of rounds 1-2
+    (`NAF_CFG_ENCODE_TWO_GATHERS`): bit-identical, including tables so small that windows are clamped at the table's end;
+  * the volume query in ranges (`naf_field_forward_grid(..., workspace_bytes)`): any workspace cap gives the same bits, and a
+    1024^3 query with a T = 2^22 table (foot_50, train.py:246-250) runs inside the default 1 GiB forward workspace.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from _naf_helpers import crossing_rays, naf_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused
+    return _abi, fused
+
+
+def _render(net, rays, S, flags, t_rand=None, perturb=True, samples=False, mlp_precision=None):
+    """naf_render_forward(_samples) with an explicit cfg.flags -> acc (, sigma, depth)."""
+    _abi, fused = _mods()
+    cfg = fused.render_cfg(net, S, perturb, mlp_precision, seed=5, flags=flags)
+    n = rays.shape[0]
+    ws = torch.empty(int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), n * S)), dtype=torch.uint8, device="cuda")
+    acc = torch.empty(n, device="cuda")
+    enc = net.encoder
+    args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(enc.embeddings.detach().contiguous()), _abi.ptr(enc.offsets.cuda()),
+            _abi.ptr(net.packed_mlp().detach().contiguous()), _abi.ptr(acc))
+    if not samples:
+        _abi.check(_abi.lib().naf_render_forward(*args, n, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_forward")
+        return acc
+    sigma, depth = torch.empty(n, S, device="cuda"), torch.empty(n, S, device="cuda")
+    _abi.check(_abi.lib().naf_render_forward_samples(*args, _abi.ptr(sigma), _abi.ptr(depth), n, ctypes.byref(cfg), _abi.ptr(ws),
+                                                     _abi.stream_ptr()), "render_forward_samples")
+    return acc, sigma, depth
+
+
+@pytest.mark.parametrize("table", [torch.bfloat16, torch.float16, torch.float32])
+def test_fused_forward_kernel_equals_the_two_kernel_path(table):
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=31, log2T=15, oracle=False)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.to(table)
+    prec = _abi.BF16                                           # the fused kernel is the bf16-MFMA shape, whatever the table stores
+    for n, S in ((77, 192), (3, 37), (130, 16)):               # ragged tiles, S not a multiple of 16
+        rays = crossing_rays(n, seed=n).cuda()
+        t_rand = torch.rand(n, S, device="cuda")
+        two = _render(net, rays, S, 0, t_rand, mlp_precision=prec)
+        one = _render(net, rays, S, _abi.CFG_FORWARD_FUSED, t_rand, mlp_precision=prec)
+        assert torch.equal(one, two)
+        a2, s2, d2 = _render(net, rays, S, 0, None, samples=True, mlp_precision=prec)
+        a1, s1, d1 = _render(net, rays, S, _abi.CFG_FORWARD_FUSED, None, samples=True, mlp_precision=prec)
+        assert torch.equal(a1, a2) and torch.equal(s1, s2) and torch.equal(d1, d2)
+    # point list and generated grid (front-end switch `fused.forward_fused`)
+    pts = (torch.rand(1000, 3, device="cuda") - 0.5) * 0.6
+    grid = ([-0.1, -0.12, -0.09], [0.1, 0.12, 0.09], [33, 18, 21])
+    out = {}
+    for on in (False, True):
+        fused.forward_fused = on
+        try:
+            out[on] = (fused.field_query(net, pts, mlp_precision=prec), fused.field_query_grid(net, *grid, mlp_precision=prec))
+        finally:
+            fused.forward_fused = True
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    assert float(out[True][1].std()) > 0
+
+
+def test_fused_forward_leaves_training_and_backward_alone():
+    """A cfg that carries NAF_CFG_FORWARD_FUSED must not starve a backward pass of its features: the training entry keeps the
+    two-kernel forward, and naf_render_backward recomputes features a fused forward did not store."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=3, log2T=14, oracle=False)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.to(torch.bfloat16)
+    n, S = 64, 48
+    rays, t_rand = crossing_rays(n, seed=9).cuda(), torch.rand(n, S, device="cuda")
+    grads = {}
+    for flags in (0, _abi.CFG_FORWARD_FUSED):
+        cfg = fused.render_cfg(net, S, True, None, seed=1, flags=flags)
+        ws = torch.empty(int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), n * S)), dtype=torch.uint8, device="cuda")
+        acc = torch.empty(n, device="cuda")
+        enc = net.encoder
+        emb, offs, mlp = enc.embeddings.detach().contiguous(), enc.offsets.cuda(), net.packed_mlp().detach().contiguous()
+        _abi.check(_abi.lib().naf_render_forward(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(emb), _abi.ptr(offs), _abi.ptr(mlp),
+                                                 _abi.ptr(acc), n, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "fwd")
+        g_emb = torch.zeros(emb.shape, device="cuda")
+        g_mlp = torch.zeros(_abi.MLP_PARAMS, device="cuda")
+        dacc = torch.linspace(-1, 1, n, device="cuda")
+        _abi.check(_abi.lib().naf_render_backward(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(dacc), _abi.ptr(emb), _abi.ptr(offs),
+                                                  _abi.ptr(mlp), _abi.ptr(g_emb), _abi.ptr(g_mlp), n, ctypes.byref(cfg), _abi.ptr(ws),
+                                                  1, _abi.stream_ptr()), "bwd")
+        grads[flags] = (acc.clone(), g_emb, g_mlp)
+    for a, b in zip(grads[0], grads[_abi.CFG_FORWARD_FUSED]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6 * float(b.abs().max()))
+    assert torch.equal(grads[0][0], grads[_abi.CFG_FORWARD_FUSED][0]) and torch.equal(grads[0][2], grads[_abi.CFG_FORWARD_FUSED][2])
+
+
+@pytest.mark.parametrize("table,C,log2T", [(torch.bfloat16, 2, 15), (torch.float16, 2, 4), (torch.float32, 2, 15), (torch.float32, 1, 6),
+                                           (torch.bfloat16, 4, 12), (torch.float32, 2, 3), (torch.bfloat16, 2, 19)])
+def test_window_gathers_equal_two_gathers(table, C, log2T):
+    """encode_kernel with one 16-byte window per x-neighbour pair against two gathers per pair: the same features, hence the
+    same bits after the MLP -- also where the window is clamped at the end of a tiny table (log2T 3..6) and for 8-byte rows."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=11, log2T=log2T, L=32 // C, C=C, oracle=False)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.to(table)
+    prec = _abi.F32 if table == torch.float32 else _abi.BF16
+    n, S = 96, 64
+    rays, t_rand = crossing_rays(n, seed=2).cuda(), torch.rand(n, S, device="cuda")
+    a = _render(net, rays, S, 0, t_rand, mlp_precision=prec)
+    b = _render(net, rays, S, _abi.CFG_ENCODE_TWO_GATHERS, t_rand, mlp_precision=prec)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    # caller-supplied coordinates on the faces / corners of the volume (largest cell indices of every level)
+    pts = torch.tensor([[0.3, 0.3, 0.3], [-0.3, -0.3, -0.3], [0.3, -0.3, 0.3], [0.29999, 0.3, 0.1]], device="cuda")
+    pts = torch.cat([pts, (torch.rand(500, 3, device="cuda") - 0.5) * 0.6])
+    out = {}
+    fused.forward_fused = False
+    try:
+        for flags in (0, _abi.CFG_ENCODE_TWO_GATHERS):
+            with fused.scatter_mode(_abi.SCATTER_AUTO, flags=flags):
+                out[flags] = fused.field_query(net, pts, mlp_precision=prec)
+    finally:
+        fused.forward_fused = True
+    assert torch.equal(out[0], out[_abi.CFG_ENCODE_TWO_GATHERS])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_volume_query_in_ranges_is_bit_identical(prec):
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=4, log2T=15, oracle=False)
+    if prec == "bf16":
+        net.encoder.embeddings.data = net.encoder.embeddings.data.to(torch.bfloat16)
+    grid = ([-0.2, -0.25, -0.15], [0.2, 0.25, 0.15], [96, 80, 112])           # 860 160 points
+    for on in (True, False):
+        fused.forward_fused = on
+        try:
+            whole = fused.field_query_grid(net, *grid, workspace_cap=1 << 40)
+            for cap in (64 << 20, 13 << 20, 300_000):
+                assert torch.equal(fused.field_query_grid(net, *grid, workspace_cap=cap), whole)
+        finally:
+            fused.forward_fused = True
+    pts = (torch.rand(200_000, 3, device="cuda") - 0.5) * 0.6
+    cap = fused.FORWARD_WORKSPACE_CAP
+    try:
+        whole = fused.field_query(net, pts)
+        fused.FORWARD_WORKSPACE_CAP = 3 << 20
+        fused.forward_fused = False
+        assert torch.equal(fused.field_query(net, pts), whole)
+        rays = crossing_rays(3000, seed=8).cuda()
+        with torch.no_grad():
+            fused.FORWARD_WORKSPACE_CAP = cap
+            full = fused.fused_render(rays, net, 64, True, seed=3)
+            fused.FORWARD_WORKSPACE_CAP = 3 << 20
+            assert torch.equal(fused.fused_render(rays, net, 64, True, seed=3), full)
+    finally:
+        fused.FORWARD_WORKSPACE_CAP, fused.forward_fused = cap, True
+
+
+def test_foot_size_volume_query_runs_inside_the_forward_workspace_cap():
+    """config/foot_50.yaml: 1024^3 voxels, T = 2^22, fp32 tables by default.  The query must run in the capped forward workspace
+    (round 2: one un-chunked call wanted 368 GiB) and agree with the point-list query on probe slices."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=6, log2T=22, scale=1e-2, oracle=False)
+    n = 1024
+    s = 0.128 - 0.128 / n
+    fused._workspaces.clear()
+    torch.cuda.empty_cache()
+    fused.forward_fused = False                             # fp32 mode has no fused kernel anyway; make the intent explicit
+    try:
+        vol = fused.field_query_grid(net, [-s] * 3, [s] * 3, [n, n, n])
+    finally:
+        fused.forward_fused = True
+    assert vol.shape == (n, n, n)
+    assert fused._workspaces[vol.device].numel() <= fused.FORWARD_WORKSPACE_CAP
+    ax = torch.tensor(np.linspace(-s, s, n), dtype=torch.float32, device="cuda")
+    for i0 in (0, 517, 1023):
+        X, Y, Z = torch.meshgrid(ax[i0:i0 + 1], ax[::64], ax, indexing="ij")
+        want = fused.field_query(net, torch.stack([X, Y, Z], -1)).squeeze(-1)
+        assert torch.equal(vol[i0:i0 + 1, ::64, :], want)
+    assert bool(torch.isfinite(vol).all())
