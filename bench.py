@@ -31,6 +31,10 @@ CHEST = dict(n_voxel=256, n_proj=50, n_samples=192, num_levels=16, level_dim=2, 
              bound=0.3, lr=1e-3, yaml_rays=1024)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 RAYS_PER_PROJECTION = 16384    # a step of n rays draws from n / 16384 consecutive projections (the YAML step: 1024 from one)
+# PSNR races run with every N = 1 bench (time / rays / steps to 30, 35, 38 dB volume PSNR from scratch): the reference's operating
+# point (config/chest_50.yaml:29-30: 1024 rays, lr 1e-3) as the control, the same step at the learning rate that wins the grid of
+# profiles/round3_psnr_race_grid.jsonl (an extension: the reference never changes lr), and the large batch at ITS best rate.
+RACES = {"yaml_step_reference_lr": (1024, 1e-3), "yaml_step_lr_4e-3": (1024, 4e-3), "large_batch_16384_lr_4e-3": (16384, 4e-3)}
 
 
 def algorithmic_bytes_per_point(kernel, table_bytes, feat_bytes, L=16, C=2, D=3):
@@ -249,7 +253,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step (chest_50.yaml uses 1024)")
+    ap.add_argument("--rays", type=int, default=CHEST["yaml_rays"],
+                    help="rays per GPU per step (default: chest_50.yaml's n_rays = 1024, the step that reconstructs fastest)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16", help="table storage / MLP operand type")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--sub-records", type=int, default=1, help="0: skip the fp32-parity-mode and 1024-ray sub-records (N = 1 only)")
@@ -265,12 +270,17 @@ def main():
     ap.add_argument("--two-gathers", action="store_true",
                     help="diagnostics: the encoder fetches x-neighbour corners with two gathers instead of one 16-byte window "
                          "(NAF_CFG_ENCODE_TWO_GATHERS)")
+    ap.add_argument("--window4", action="store_true", help="diagnostics: NAF_CFG_ENCODE_WINDOW4")
+    ap.add_argument("--split2x", action="store_true", help="diagnostics: NAF_CFG_BACKWARD_SPLIT_2X")
+    ap.add_argument("--xcd-pinned", action="store_true", help="NAF_CFG_LEVELS_XCD_PINNED: the encoder gives XCD k the levels k, k + 8")
     ap.add_argument("--separate-adam", action="store_true",
                     help="diagnostics: write the table gradient out and run the table's Adam pass as its own launch "
                          "(default: the gradient reducer applies it, naf_render_train_adam)")
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
                          "stream, per-bucket Adam) with a world-size-1 process group")
+    ap.add_argument("--dp-mode", choices=["sharded", "allreduce"], default="sharded",
+                    help="N > 1: reduce-scatter -> per-rank Adam on a table slice -> all-gather (default), or all-reduce + replicated Adam")
     ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,4-8,0-4 (the default)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
@@ -325,8 +335,8 @@ def main():
                                  n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
                                  scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
                                  cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
-                                           | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0),
-                                 bucket_levels=buckets, fuse_table_adam=not args.separate_adam)
+                                           | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOW4 if args.window4 else 0) | (_abi.CFG_BACKWARD_SPLIT_2X if args.split2x else 0) | (_abi.CFG_LEVELS_XCD_PINNED if args.xcd_pinned else 0),
+                                 bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode)
 
     engine = make_engine(args.precision, pg)
     allreduce_bytes = engine.grad_flat.numel() * 4
@@ -334,7 +344,7 @@ def main():
     n = args.rays
     total_steps = args.warmup + args.steps
     rays = torch.empty(n, 8, device=device)
-    weight = torch.full((n,), 1.0 / (n * world), device=device)       # global mean over all ranks' rays
+    weight, loss_name = step_weights(n, device, world)               # N > 1: global mean over all ranks' rays
 
     def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
         # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip)
@@ -355,25 +365,35 @@ def main():
             log("first step done")
     barrier()
     log(f"timing {args.steps} steps")
-    engine.comm_timing(True)
-    _abi.profile_enable(True)
+    # ---- the timed region: exactly K steps, nothing but the step inside (no event pairs around kernels: at 0.3 ms per step they
+    # would be a tenth of what is measured) ------------------------------------------------------------------------------
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         loss = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = _abi.profile_collect()
-    _abi.profile_enable(False)
-    comm = engine.comm_report()
-    engine.comm_timing(False)
-    log(f"timed region {elapsed:.3f} s")
+    log(f"timed region {elapsed:.4f} s")
     final_loss = float(loss.item())
-    overflow = engine.scatter_overflow(n)
-
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- per-kernel times: a second pass over the same kind of steps with a HIP-event pair around every kernel, on its launch
+    # stream (naf_profile_*).  The events cost ~10 % at this step size, which is why this pass is not the timed region. ----------
+    prof_steps = max(args.steps, 50 if n <= 4096 else 10)
+    engine.comm_timing(True)
+    _abi.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(total_steps, total_steps + prof_steps):
+        step(i)
+    barrier()
+    prof_elapsed = time.perf_counter() - t0
+    prof = _abi.profile_collect()
+    _abi.profile_enable(False)
+    comm = engine.comm_report()
+    engine.comm_timing(False)
+    overflow = engine.scatter_overflow(n)
 
     def timed(fn, steps, warm):
         for i in range(warm):
@@ -385,38 +405,68 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / steps
 
+    sustained = None
+    if world == 1 and not args.force_dp:
+        k = max(args.steps, int(2.2 / (elapsed / args.steps)))           # >= 2 s of back-to-back steps
+        dt = timed(lambda i: step(total_steps + prof_steps + i), k, 0)
+        sustained = {"steps": k, "seconds": round(dt * k, 3), "ms_per_step": round(dt * 1e3, 4), "rays_per_s": n / dt}
+        log(f"sustained: {k} steps in {dt * k:.2f} s")
+
     sub_records = None
     if rank == 0 and world == 1 and args.sub_records and not args.force_dp:
-        log("sub-records: the YAML's 1024-ray step, the fp32 parity mode")
-        # (a) the YAML's own step: 1 024 rays of ONE projection, the reference's chunk-sum loss (train.py:69,127)
-        m = CHEST["yaml_rays"]
-        r1 = torch.empty(m, 8, device=device)
-        w1, _ = step_weights(m, device)
-        dt = timed(lambda i: step(i, engine, m, r1, w1), 200, 20)
-        sub_records = {"yaml_step_1024_rays": {"rays_per_step": m, "precision": args.precision, "ms_per_step": round(dt * 1e3, 4),
-                                               "rays_per_s": m / dt, "loss": "chunk_sum (sum of 200-ray chunk means)"}}
+        log("sub-records: the large batch, the fp32 parity mode")
+        # (a) the throughput end of the batch curve (the headline of rounds 1-2): 65 536 rays from 4 projections per step
+        sub_records = {}
+        if n != 65536:
+            m = 65536
+            r1, (w1, _) = torch.empty(m, 8, device=device), step_weights(m, device)
+            dt = timed(lambda i: step(i, engine, m, r1, w1), 20, 3)
+            sub_records["large_batch_65536_rays"] = {"rays_per_step": m, "precision": args.precision, "ms_per_step": round(dt * 1e3, 4),
+                                                     "rays_per_s": m / dt, "loss": "global mean"}
+            del r1, w1
         # (b) the reference's arithmetic: fp32 table, fp32 MFMA (bit-for-bit an fmaf chain), fp32 scatter records
         if args.precision == "bf16":
             e32 = make_engine("fp32", None)
-            m = 16384
-            r2, w2 = torch.empty(m, 8, device=device), torch.full((m,), 1.0 / m, device=device)
-            dt = timed(lambda i: step(i, e32, m, r2, w2), 10, 3)
-            sub_records["fp32_parity_mode_16384_rays"] = {"rays_per_step": m, "precision": "fp32", "ms_per_step": round(dt * 1e3, 4),
-                                                           "rays_per_s": m / dt}
+            for m, steps in ((CHEST["yaml_rays"], 300), (16384, 10)):
+                r2, (w2, ln) = torch.empty(m, 8, device=device), step_weights(m, device)
+                dt = timed(lambda i: step(i, e32, m, r2, w2), steps, 5)
+                sub_records[f"fp32_parity_mode_{m}_rays"] = {"rays_per_step": m, "precision": "fp32", "ms_per_step": round(dt * 1e3, 4),
+                                                             "rays_per_s": m / dt, "loss": ln}
             del e32
+        torch.cuda.empty_cache()
+
+    # ---- the PSNR half of the metric: time / rays / steps to 30, 35, 38 dB volume PSNR, from scratch, per operating point -------
+    psnr = None
+    if rank == 0 and world == 1 and args.psnr_seconds > 0 and not args.force_dp:
+        psnr = {}
+        for name, (m, lr) in RACES.items():
+            log(f"PSNR race {name}: {m} rays/step, lr {lr}")
+            psnr[name] = psnr_race(scan, m, lr, args.precision, max_train_s=args.psnr_seconds)
+            log(f"  -> {psnr[name]['time_to_psnr']}")
 
     if rank == 0:
         rays_total = world * n * args.steps
         points_per_launch = n * CHEST["n_samples"]
-        sizes = {"bf16": (2, 2), "fp32": (4, 4)}[args.precision]
-        kernels = {k: {"launches": c, "total_ms": ms} for k, (c, ms) in prof.items()}
-        groups = {"hash_forward": ["encode_kernel"], "hash_backward": ["hash_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel"],
-                  "mlp_forward": ["mlp_forward_kernel"], "mlp_backward": ["mlp_backward_kernel", "mlp_grad_reduce_kernel"],
-                  "adam": ["adam_kernel"]}
-        ms_per_step = {g: sum(v["total_ms"] for k, v in kernels.items() if any(k.startswith(m) for m in members)) / args.steps
-                       for g, members in groups.items()}
-        ms_per_step = {g: v for g, v in ms_per_step.items() if v > 0}
+        n_params = engine.emb.numel()
+        tb, fb = {"bf16": (2, 2), "fp32": (4, 4)}[args.precision]
+        kernels = {k: {"launches": c, "total_ms": ms, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         mfma_peak = 2500.0 if args.precision == "bf16" else 157.3      # TFLOP/s dense, MI355X_MICROARCH.md
+        rec_bytes = 12 if args.precision == "bf16" else 20             # pair record of the binned scatter (scatter_binned.h)
+        fused_adam = engine.fuse_table_adam and engine._dp is None
+        # Algorithmic bytes / flops of ONE launch of each kernel.  encode: SURVEY 8(d)'s hash-forward figure.
+        # The gradient scatter is two kernels here, each priced on what it must move: bin reads the feature gradients and writes
+        # one pair record per x-neighbour corner pair; reduce reads the records and -- with the Adam tail -- reads and writes
+        # parameter, both moments (fp32) and writes the 16-bit shadow of every table element (otherwise read + write of the gradient).
+        algo = {
+            "encode_kernel": ("hbm", algorithmic_bytes_per_point("encode_kernel", tb, fb) * points_per_launch),
+            "scatter_bin_kernel": ("hbm", (32 * fb + 16 * 4 * rec_bytes) * points_per_launch),
+            "scatter_reduce_kernel": ("hbm", 16 * 4 * rec_bytes * points_per_launch
+                                      + n_params * ((24 + (2 if args.precision == "bf16" else 0)) if fused_adam else 8)),
+            "hash_backward_kernel": ("hbm", algorithmic_bytes_per_point("hash_backward_kernel", tb, fb) * points_per_launch),
+            "mlp_forward_kernel": ("mfma", 8256 * points_per_launch),
+            "mlp_backward_kernel": ("mfma", 3 * 8256 * points_per_launch),
+            "adam_kernel": ("hbm", None),
+        }
 
         # HBM bytes by PMC counters come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); they are printed only
         # while the kernel sources are the ones those passes ran on
@@ -427,61 +477,72 @@ def main():
             if doc.get("csrc_fingerprint") != source_fingerprint():
                 traffic_note = (f"stale: the PMC passes ran on kernel sources {doc.get('csrc_fingerprint')}, this build is "
                                 f"{source_fingerprint()} -- rerun tools/collect_profiles.sh + tools/install_profiles.py")
-            elif n != 65536 or world != 1:
-                traffic_note = "the PMC passes were taken at 65536 rays/step on one GPU"
+            elif n != doc.get("rays_per_step", 65536) or world != 1:
+                traffic_note = f"the PMC passes were taken at {doc.get('rays_per_step', 65536)} rays/step on one GPU"
             else:
                 traffic_table = doc.get(args.precision, {})
                 traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {doc.get('collected_at_commit')}, "
                                 f"kernel sources {doc.get('csrc_fingerprint')}")
 
-        def roof(group):
-            t = ms_per_step[group] * 1e-3
-            members = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in kernels.items()
-                       if any(k.startswith(m) for m in groups[group])}
-            base = {"kernel": group, "per_step_ms": round(ms_per_step[group], 4), "points_per_step": points_per_launch,
-                    "member_kernels_avg_launch_ms": members}       # HIP-event average per launch; compare with the rocprofv3 CSV
-            if group in ("hash_forward", "hash_backward"):
-                bytes_pp = algorithmic_bytes_per_point("encode_kernel" if group == "hash_forward" else "hash_backward_kernel", *sizes)
-                achieved = bytes_pp * points_per_launch / t / 1e9
-                base.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_table.get(group),
-                             "algorithmic_bytes_per_point": bytes_pp})
+        def roof(kernel):
+            """Roofline of ONE kernel: algorithmic bytes (or flops) of a launch / its average launch duration (HIP events on the
+            launch stream, profiled pass); `traffic` = HBM bytes per launch by PMC; `real_frac` = traffic / time / peak."""
+            v = kernels[kernel]
+            t = v["avg_ms"] * 1e-3
+            bound, work = algo.get(kernel, ("hbm", None))
+            base = {"kernel": kernel, "avg_launch_ms": round(v["avg_ms"], 5), "launches_per_step": round(v["launches"] / prof_steps, 2),
+                    "points_per_launch": points_per_launch, "bound": bound}
+            if work is None:
+                return base
+            if bound == "hbm":
+                ach = work / t / 1e9
+                traffic = traffic_table.get(kernel)
+                base.update({"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                             "traffic": traffic, "algorithmic_bytes_per_launch": work,
+                             "real_frac": None if not traffic else round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)})
             else:
-                flops_pp = {"mlp_forward": 8256, "mlp_backward": 3 * 8256}[group]
-                achieved = flops_pp * points_per_launch / t / 1e12
-                base.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": mfma_peak, "unit": "TFLOP/s",
-                             "frac": round(achieved / mfma_peak, 4), "traffic": None, "algorithmic_flops_per_point": flops_pp})
+                ach = work / t / 1e12
+                base.update({"achieved": round(ach, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4),
+                             "traffic": None, "algorithmic_flops_per_launch": work})
             return base
 
-        dominant = max((g for g in ms_per_step if g != "adam"), key=lambda g: ms_per_step[g])
-        kernel_ms = sum(v["total_ms"] for v in kernels.values()) / args.steps
+        per_step = {k: v["total_ms"] / prof_steps for k, v in kernels.items()}
+        dominant = max((k for k in per_step if k in algo and algo[k][1] is not None), key=lambda k: per_step[k])
+        kernel_ms = sum(per_step.values())
         out = {
             "metric": "train rays/sec, chest 256^3 / 50 proj", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"chest_50.yaml: 256^3 volume, 50 cone-beam projections 512x512, hash L=16 T=2^19 C=2 "
-                                   f"({args.precision} table), S=192, MLP 32-32-32-(64)-32-1, Adam; "
+                                   f"({args.precision} table), S=192, MLP 32-32-32-(64)-32-1, Adam lr {engine.lr:g}; "
                                    f"{n} rays/step/GPU (reference n_rays=1024) = {min(n, RAYS_PER_PROJECTION)} distinct valid pixels from "
-                                   f"each of {max(1, n // RAYS_PER_PROJECTION)} projections, drawn on the device inside the step; perturb=True",
-                       "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "parallelism": f"dp{world}"},
-            "final_loss": final_loss, "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n),
-            "scatter_overflow_fraction": overflow / (points_per_launch * 128.0),
+                                   f"{'one projection' if n <= RAYS_PER_PROJECTION else f'each of {n // RAYS_PER_PROJECTION} projections'}, "
+                                   f"drawn on the device inside the step; perturb=True; loss: {loss_name}"
+                                   + ("; the operating point that reaches 35 dB volume PSNR soonest (psnr.*, profiles/round3_psnr_race_grid.jsonl)"
+                                      if n == CHEST["yaml_rays"] else ""),
+                       "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "lr": engine.lr, "parallelism": f"dp{world}"},
+            "final_loss": final_loss, "sustained": sustained, "psnr": psnr,
+            "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n),
             "library_kernels_ms_per_step": round(kernel_ms, 4),
-            "sampling_and_gaps_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 4),
+            "profiled_pass": {"steps": prof_steps, "ms_per_step": round(prof_elapsed / prof_steps * 1e3, 4),
+                              "note": "per-kernel HIP-event pairs switched on; not the timed region"},
             "allreduce_ms_per_step": None, "allreduce_exposed_ms_per_step": None, "allreduce_buckets": dp_buckets,
-            "allreduce_bytes": allreduce_bytes,
+            "allreduce_bytes": allreduce_bytes, "rays_per_s_per_gpu": rays_total / elapsed / world,
+            "grad_exchange": None if engine._dp is None else (
+                "reduce-scatter of the table gradient -> Adam on this rank's 1/N slice -> all-gather of the table the kernels read; "
+                "MLP gradient + loss all-reduced" if engine.dp_mode == "sharded" else "all-reduce per level bucket, Adam replicated"),
             "roofline": roof(dominant),
-            "roofline_hash_forward": roof("hash_forward"),
-            "roofline_all": {g: roof(g) for g in ms_per_step if g != "adam"},
+            "roofline_hash_forward": roof("encode_kernel") if "encode_kernel" in kernels else None,
+            "roofline_all": {k: roof(k) for k in sorted(kernels) if k in algo},
             "traffic_source": traffic_note,
-            "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernels.items())},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
         }
         if comm is not None:
-            # in flight: the collectives on the side stream, measured by events inside the timed steps.  exposed: what the main
+            # in flight: the collectives on the side stream, measured by events inside the profiled steps.  exposed: what the main
             # stream waited after its own compute = tail (end of compute -> last Adam launched) minus the Adam kernels themselves
             out["allreduce_ms_per_step"] = round(comm["allreduce_ms_per_step"], 4)
-            out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - ms_per_step.get("adam", 0.0)), 4)
+            out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - per_step.get("adam_kernel", 0.0)), 4)
         if sub_records is not None:
             out["sub_records"] = sub_records
         if world == 1 and args.cpu_seconds > 0 and not args.force_dp:

@@ -195,6 +195,9 @@ typedef struct naf_render_cfg {
                                          need no workspace (naf_forward_workspace_bytes).  Bit-identical to the two-kernel path. */
 #define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
                                          (rounds 1-2) instead of one 16-byte window (same results; A/B timing only)      */
+#define NAF_CFG_BACKWARD_SPLIT_2X 128u /* diagnostics: the MLP backward splits rays into tile ranges up to two waves per SIMD          */
+#define NAF_CFG_LEVELS_XCD_PINNED 256u /* the encoder gives XCD k the levels k, k + 8, ... (see encode_kernel)                        */
+#define NAF_CFG_ENCODE_WINDOW4 64u     /* diagnostics: four points per thread in the window encoder instead of two                 */
 #define NAF_CFG_FUSED_STORE_FEATURES 16u /* diagnostics: the fused kernel also stores the features it computed              */
 
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
@@ -291,7 +294,7 @@ int naf_field_forward_grid(const double *start, const double *stop, const uint32
  * clear -- the 57 MB (T=2^19) gradient table is then neither written, re-read nor zeroed.  Same results, bit for bit, as
  * naf_render_train followed by naf_adam_step(param, exp_avg, exp_avg_sq, grad_embeddings, param_lp, lp_dtype, n, ...,
  * zero_grad = 1): `grad_embeddings` must be all zero on entry and is all zero on return; the MLP gradient and the loss are
- * written as usual (the caller steps the 4 225 MLP parameters with naf_adam_step).  Batches that take the atomic scatter
+ * written as usual (the caller steps the 4 225 MLP parameters with naf_adam_step, or hands their state over in `adam`).  Batches that take the atomic scatter
  * (< 2^13 points) or split reducer launches run the two passes one after the other inside the call.
  * `embeddings` is what the kernels gather from (the 16-bit shadow `param_lp` in 16-bit mode, `param` itself in fp32 mode). */
 typedef struct naf_table_adam {
@@ -304,6 +307,11 @@ typedef struct naf_table_adam {
     float lr, beta1, beta2, eps;
     uint32_t step;         /* 1-based */
     float grad_scale;      /* gradient multiplier (1 unless the loss was scaled) */
+    /* Optional: the MLP's Adam state (4 225 fp32 values each, same hyper-parameters and step).  With mlp_param set (it must be
+     * the `mlp` block the call reads) the reduction of the weight-gradient slabs applies the MLP's update itself: grad_mlp is
+     * consumed (+= semantics: whatever it held is added first) and left zero, bit for bit what naf_adam_step(mlp ..., zero_grad
+     * = 1) after the call would have done.  NULL: grad_mlp is written as usual and the caller steps the MLP. */
+    float *mlp_param, *mlp_exp_avg, *mlp_exp_avg_sq;
 } naf_table_adam;
 int naf_render_train_adam(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
                           const void *embeddings, const int32_t *offsets, const float *mlp, float *acc, float *grad_embeddings,

@@ -23,6 +23,9 @@ CFG_LEVELS_INTERLEAVED = 4
 CFG_FORWARD_FUSED = 8
 CFG_FUSED_STORE_FEATURES = 16
 CFG_ENCODE_TWO_GATHERS = 32
+CFG_ENCODE_WINDOW4 = 64
+CFG_BACKWARD_SPLIT_2X = 128
+CFG_LEVELS_XCD_PINNED = 256
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -61,6 +64,7 @@ class TableAdam(ctypes.Structure):
         ("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("param_lp", ctypes.c_void_p),
         ("lp_dtype", ctypes.c_int32), ("n", ctypes.c_uint64), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
         ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("step", ctypes.c_uint32), ("grad_scale", ctypes.c_float),
+        ("mlp_param", ctypes.c_void_p), ("mlp_exp_avg", ctypes.c_void_p), ("mlp_exp_avg_sq", ctypes.c_void_p),
     ]
 
 

@@ -8,11 +8,10 @@
 // Kernels of one training step (B = n_rays * S points, feature tensors are [L, B, C]):
 //   1 encode_kernel                  gathers  -> feat                 level-major, four points per lane
 //   2 mlp_forward_kernel             feat -> sigma -> acc[r]          one wave per ray, wave-reduced line integral
-//   - loss_grad_kernel               acc, target, weight -> d loss / d acc, loss
-//   3 mlp_backward_kernel            feat, d acc -> dfeat, per-workgroup dW slabs
+//   3 mlp_backward_kernel            feat, (acc, target, weight | d acc) -> dfeat, per-workgroup dW slabs + loss share
 //   4 scatter_bin / scatter_reduce / scatter_apply (scatter_binned.h)   dfeat -> grad table, no global atomics;
 //     hash_backward_kernel<SrcRays> (hash_kernels.h, fp32 atomics like the reference) below 2^13 points per call
-//   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=)
+//   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=) or the MLP's Adam update, loss (+=)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -341,6 +340,15 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
 // ---- 3: MLP backward --------------------------------------------------------------------------------------
 // slab layout == parameter block layout (kW0 .. kB3), one slab of kSlabStride floats per workgroup.
 constexpr uint32_t kSlabStride = 4352;
+constexpr uint32_t kSlabLoss = kMlpParams;         // slab entry behind the parameter block: the workgroup's share of the loss
+
+// Training steps hand the backward kernels what the loss needs instead of a precomputed d loss / d acc: the masked squared error
+// of train.py:127 / loss.py:37 in weighted form, loss = sum_r w_r (acc_r - y_r)^2, d loss / d acc_r = 2 w_r (acc_r - y_r), is two
+// flops per ray -- a kernel launch of its own (loss_grad_kernel) cost a fortieth of the reference-size step.
+struct LossInputs { const float *acc, *target, *weight; };
+// ... and the reduction of the weight-gradient slabs applies the MLP's Adam update to the sums it has just formed
+// (naf_render_train_adam with mlp_param set) instead of writing them out for one more launch to read back.
+struct MlpAdam { float *param, *m, *v; AdamArgs a; };
 
 template <typename P>
 __device__ __forceinline__ void wave_lds_fence() {
@@ -352,7 +360,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <typename P, uint32_t C>
 __global__ void __launch_bounds__(256)
 mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
-                    const float *__restrict__ grad_acc, typename P::feat_t::store_t *__restrict__ dfeat,
+                    const float *__restrict__ grad_acc, LossInputs loss, typename P::feat_t::store_t *__restrict__ dfeat,
                     float *__restrict__ slabs, uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act) {
     using Sh = MlpShared<P>;
     using TR = typename P::tr_t;
@@ -374,6 +382,7 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
     float db0 = 0.0f, db1 = 0.0f, db2 = 0.0f, db3 = 0.0f;
     uint32_t dmax = 0u;                                      // bit pattern of max |feature gradient| (scale of the binned scatter);
                                                              // compared as integers so that Inf / NaN win and stay visible
+    float loss_part = 0.0f;                                  // this wave's rays: sum w (acc - y)^2
     float dw3[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) dw3[t] = 0.0f;
@@ -387,7 +396,12 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
         const float *ray = src.rays + (size_t)r * 8;
         const float near = ray[6], far = ray[7];
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
-        const float dacc = grad_acc[r];
+        float dacc;
+        if (loss.target != nullptr) {                        // training step: the loss lives here (wave-uniform arithmetic)
+            const float err = loss.acc[r] - loss.target[r], w = loss.weight[r];
+            dacc = 2.0f * w * err;
+            loss_part += w * err * err;
+        } else dacc = grad_acc[r];
         if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
 
         for (uint32_t k = 0; k < tiles; ++k) {
@@ -506,56 +520,19 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
                 red[kB1 + n] = (first ? 0.0f : red[kB1 + n]) + db1;
                 red[kB2 + n] = (first ? 0.0f : red[kB2 + n]) + db2;
             }
-            if (lane == 0) red[kB3] = (first ? 0.0f : red[kB3]) + db3;
+            if (lane == 0) { red[kB3] = (first ? 0.0f : red[kB3]) + db3; red[kSlabLoss] = (first ? 0.0f : red[kSlabLoss]) + loss_part; }
         }
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
-    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) slab[i] = red[i];
-}
-
-// masked squared error of train.py:127 / loss.py:37 in weighted form: loss = sum_r w_r (acc_r - y_r)^2,
-// grad_acc[r] = 2 w_r (acc_r - y_r).  Each workgroup takes a contiguous slice of the rays and leaves its partial sum in
-// partial[blockIdx.x]; loss_sum_kernel adds the partials in index order (deterministic).  One workgroup (small batches)
-// adds straight into loss_out.
-constexpr uint32_t kLossBlocks = 64;
-__global__ void __launch_bounds__(1024)
-loss_grad_kernel(const float *__restrict__ acc, const float *__restrict__ target, const float *__restrict__ ray_weight,
-                 float *__restrict__ grad_acc, float *__restrict__ loss_out, float *__restrict__ partial, uint32_t n_rays) {
-    __shared__ float part[16];
-    const uint32_t per_block = (n_rays + gridDim.x - 1u) / gridDim.x;
-    const uint32_t begin = blockIdx.x * per_block, end = min(n_rays, begin + per_block);
-    float s = 0.0f;
-    for (uint32_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
-        const float err = acc[r] - target[r], w = ray_weight[r];
-        grad_acc[r] = 2.0f * w * err;
-        s += w * err * err;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.0f;
-        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) t += part[i];
-        if (gridDim.x == 1u) { if (loss_out != nullptr) loss_out[0] += t; }
-        else partial[blockIdx.x] = t;
-    }
-}
-__global__ void __launch_bounds__(64)
-loss_sum_kernel(const float *__restrict__ partial, uint32_t n, float *__restrict__ loss_out) {
-    if (threadIdx.x == 0) {
-        float t = 0.0f;
-        for (uint32_t i = 0; i < n; ++i) t += partial[i];
-        loss_out[0] += t;
-    }
+    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) slab[i] = red[i];
 }
 
 // ---- 3b: MLP backward on 16-point tiles (bf16 mode, C = 2; field_mlp16.h) ----------------------------------------
 // Same outputs as mlp_backward_kernel (dfeat, one dW slab per workgroup, max |dfeat|) at two or more waves per SIMD.
 __global__ void __launch_bounds__(256, 3)                     // 168 VGPRs (11 spilled dwords): three waves per SIMD
 mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
-                      const float *__restrict__ grad_acc, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
+                      const float *__restrict__ grad_acc, LossInputs loss, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
                       uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act, uint32_t log2_parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Mlp16Shared::build(smem, mlp, 8);
@@ -582,7 +559,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         for (int q = 0; q < 4; ++q) dW2[o][q] = zero4;
     }
     float db[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};                 // per lane: output 16o + (lane & 15), its 4 points
-    float db3 = 0.0f;
+    float db3 = 0.0f, loss_part = 0.0f;
     uint32_t dmax = 0u;                                      // see mlp_backward_kernel
     f32x4v dw3lo = zero4, dw3hi = zero4;
 
@@ -599,7 +576,12 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         const float *ray = src.rays + (size_t)r * 8;
         const float near = ray[6], far = ray[7];
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
-        const float dacc = grad_acc[r];
+        float dacc;
+        if (loss.target != nullptr) {                        // training step: the loss lives here (wave-uniform arithmetic)
+            const float err = loss.acc[r] - loss.target[r], w = loss.weight[r];
+            dacc = 2.0f * w * err;
+            if ((item & part_mask) == 0u) loss_part += w * err * err;      // once per ray, not once per tile range
+        } else dacc = grad_acc[r];
         if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
 
         for (uint32_t k = k_begin; k < k_end; ++k) {
@@ -732,7 +714,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     }
     __syncthreads();                                                                // images / depth buffers are dead
     float *red = reinterpret_cast<float *>(smem + kShAligned);
-    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) red[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) red[i] = 0.0f;
     __syncthreads();
     for (uint32_t w = 0; w < 4u; ++w) {
         if (wib == w) {
@@ -764,25 +746,27 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
                     red[kW3 + 16u + 4u * g + j] += dw3hi[j];
                 }
             }
-            if (lane == 0u) red[kB3] += db3;
+            if (lane == 0u) { red[kB3] += db3; red[kSlabLoss] += loss_part; }
         }
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
-    for (uint32_t i = threadIdx.x; i < kMlpParams; i += blockDim.x) slab[i] = red[i];
+    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) slab[i] = red[i];
 }
 
-// ---- 5: slabs -> grad_mlp (+=), summed in a fixed order (deterministic) ---------------------------------------
-// 256 threads = 32 parameters x 8 slab groups: group g adds slabs g, g+8, ... (four independent chains), the eight
-// partial sums are combined through LDS in group order.
-constexpr uint32_t kReduceParams = 32, kReduceGroups = 8;
-__global__ void __launch_bounds__(256)
-mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp) {
+// ---- 5: slabs -> grad_mlp (+=) and loss (+=), summed in a fixed order (deterministic) ---------------------------------
+// 1024 threads = 32 entries x 32 slab groups: group g adds slabs g, g + 32, ... (four independent chains), the 32 partial sums are
+// combined through LDS in group order.  Entry kSlabLoss is the loss.  With `adam.param` set the finished sum of a parameter goes
+// straight into its Adam update (same expression as adam_kernel: adam_math.h) and the gradient buffer stays as it was.
+constexpr uint32_t kReduceParams = 32, kReduceGroups = 32;
+__global__ void __launch_bounds__(1024)
+mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp, float *__restrict__ loss_out,
+                       bool with_loss, MlpAdam adam) {
     __shared__ float part[kReduceGroups][kReduceParams];
     const uint32_t j = threadIdx.x % kReduceParams, g = threadIdx.x / kReduceParams;
     const uint32_t i = blockIdx.x * kReduceParams + j;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (i < kMlpParams) {
+    if (i <= kSlabLoss) {
         uint32_t k = g;
         for (; k + 3u * kReduceGroups < n_slabs; k += 4u * kReduceGroups) {
             s0 += slabs[(size_t)(k + 0u * kReduceGroups) * kSlabStride + i];
@@ -794,11 +778,18 @@ mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float 
     }
     part[g][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && i < kMlpParams) {
+    if (g == 0 && i <= kSlabLoss) {
         float total = 0.0f;
 #pragma unroll
         for (uint32_t q = 0; q < kReduceGroups; ++q) total += part[q][j];
-        grad_mlp[i] += total;
+        if (i == kSlabLoss) { if (with_loss && loss_out != nullptr) loss_out[0] += total; }
+        else if (adam.param != nullptr) {
+            const float gsum = grad_mlp[i] + total;          // whatever the caller had accumulated there (+=), as adam_kernel would see it
+            float p = adam.param[i], m = adam.m[i], v = adam.v[i];
+            adam_one(p, m, v, gsum, adam.a);
+            adam.param[i] = p; adam.m[i] = m; adam.v[i] = v;
+            grad_mlp[i] = 0.0f;
+        } else grad_mlp[i] += total;
     }
 }
 
@@ -920,7 +911,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_SPLIT_2X | NAF_CFG_LEVELS_XCD_PINNED)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -932,25 +923,32 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
 // features are produced by a converting instantiation below.
 __host__ __device__ constexpr uint32_t encode_points_per_thread(uint32_t C) { return C <= 2 ? 4u : C == 4 ? 2u : 1u; }
 
-template <typename TT, typename FT, uint32_t C, typename Src, bool kWindow>
+template <typename TT, typename FT, uint32_t C, typename Src, uint32_t kWindow>        // kWindow: 0 = two gathers per pair, else points per thread
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, bool interleaved, uint32_t n_levels) {
-    // level-major by default: blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and that level's
-    // slice of the table stays in the L2s.  `interleaved` (NAF_CFG_LEVELS_INTERLEAVED, a diagnostic) puts the level in x instead:
-    // every XCD then walks all levels at once -- the cache behaviour of a kernel that gathers all levels of a point tile.
-    const uint32_t level = level_base + (interleaved ? blockIdx.x : blockIdx.y);
-    const uint32_t block_x = interleaved ? blockIdx.y : blockIdx.x, grid_x = interleaved ? gridDim.y : gridDim.x;
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, uint32_t order, uint32_t n_levels, uint32_t total_levels) {
+    // order 0 -- level-major (default): blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and that
+    //   level's slice of the table stays in the L2s.
+    // order 1 -- NAF_CFG_LEVELS_INTERLEAVED (diagnostic): the level in x, every XCD walks levels k and k + 8 at once.
+    // order 2 -- XCD-pinned (small batches): workgroups go to the eight XCDs round-robin, so workgroup b belongs to XCD b % 8, which
+    //   takes the levels b % 8, b % 8 + 8, ... one after the other.  Each L2 then fills with its own levels only: a step pulls the
+    //   table through the L2s once (28.5 MB at T = 2^19, bf16) instead of once per XCD (228 MB) -- what a 1 024-ray step, whose
+    //   196 608 points touch every line of every level anyway, spends much of its encode time on.
+    const uint32_t table_rows = (uint32_t)offsets[total_levels];
+    for (uint32_t level = level_base + (order == 1u ? blockIdx.x : order == 2u ? blockIdx.x % 8u : blockIdx.y);
+         level < level_base + n_levels; level += (order == 2u ? 8u : n_levels)) {
+    const uint32_t block_x = order == 1u ? blockIdx.y : order == 2u ? blockIdx.x / 8u : blockIdx.x;
+    const uint32_t grid_x = order == 1u ? gridDim.y : order == 2u ? gridDim.x / 8u : gridDim.x;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     const uint32_t stride = grid_x * blockDim.x;
-    if constexpr (kWindow) {
+    if constexpr (kWindow != 0u) {
         // x-neighbour corners through one 16-byte window each (PairWindow, naf_device.h): 4.7 instead of 8 L1 accesses per point
         using PW = PairWindow<TT, C>;
-        constexpr uint32_t kPts = 2u;                            // 8 windows + their far rows in flight per lane
-        const uint32_t safe_last = (uint32_t)offsets[n_levels] - PW::kWin - m.offset;
+        constexpr uint32_t kPts = kWindow;                       // 2: 8 windows + their far rows in flight per lane
+        const uint32_t safe_last = table_rows - PW::kWin - m.offset;
         for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
             float w[kPts][8];
             PW pw[kPts][4];
@@ -1017,6 +1015,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     }
     }
     });
+    }
 }
 
 template <typename TT, typename P, uint32_t C, typename Src>
@@ -1024,22 +1023,27 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     using FT = typename P::feat_t;
     constexpr bool kCanWindow = PairWindow<TT, C>::kUsable;
     const bool window = kCanWindow && (cfg->flags & NAF_CFG_ENCODE_TWO_GATHERS) == 0u;
-    auto kern = encode_kernel<TT, FT, C, Src, false>;
-    if constexpr (kCanWindow) { if (window) kern = encode_kernel<TT, FT, C, Src, true>; }
-    const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
+    const bool window4 = window && (cfg->flags & NAF_CFG_ENCODE_WINDOW4) != 0u;
+    auto kern = encode_kernel<TT, FT, C, Src, 0u>;
+    if constexpr (kCanWindow) { if (window) kern = window4 ? encode_kernel<TT, FT, C, Src, 4u> : encode_kernel<TT, FT, C, Src, 2u>; }
+    const uint32_t kPts = window4 ? 4u : window ? 2u : encode_points_per_thread(C);
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
         for (uint32_t l = 0; l < cfg->L; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, false, cfg->L);
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L);
         }
         return check_launch("encode_kernel");
     }
     const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
     const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
-    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, interleaved ? dim3(cfg->L, gx) : dim3(gx, cfg->L), dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, interleaved, cfg->L); }
+    const bool pinned = !interleaved && (cfg->flags & NAF_CFG_LEVELS_XCD_PINNED) != 0u && cfg->L >= 8u;
+    const uint32_t order = interleaved ? 1u : pinned ? 2u : 0u;
+    // pinned: 8 XCDs x up to 256 workgroups each (32 CUs x 4 waves per SIMD = 8 workgroups of 4 waves per CU)
+    const dim3 grid = interleaved ? dim3(cfg->L, gx) : pinned ? dim3(8u * std::min(gx, 256u)) : dim3(gx, cfg->L);
+    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, order, cfg->L, cfg->L); }
     return check_launch("encode_kernel");
 }
 
@@ -1075,26 +1079,37 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     return check_launch("mlp_forward_kernel");
 }
 
+static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad_mlp, float *loss_out, bool with_loss, const MlpAdam *madam, hipStream_t s) {
+    const MlpAdam none{nullptr, nullptr, nullptr, AdamArgs{}};
+    ProfScope prof_("mlp_grad_reduce_kernel", s);
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kSlabLoss + 1u + kReduceParams - 1u) / kReduceParams), dim3(kReduceParams * kReduceGroups), 0, s,
+                       slabs, n_slabs, grad_mlp, loss_out, with_loss, madam != nullptr ? *madam : none);
+    return check_launch("mlp_grad_reduce_kernel");
+}
+
+// `loss.target` != nullptr: training step -- d loss / d acc is formed inside the kernel from (acc, target, weight), the loss itself
+// travels through the slabs into loss_out (+=).  Otherwise `grad_acc` is the upstream gradient (naf_render_backward).
 template <typename P, uint32_t C>
-static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, void *dfeat,
-                            float *slabs, uint32_t *gmax_bits, float *grad_mlp, uint32_t n_rays, uint32_t B, const naf_render_cfg *cfg,
-                            hipStream_t s) {
+static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, const LossInputs &loss, void *dfeat,
+                            float *slabs, uint32_t *gmax_bits, float *grad_mlp, float *loss_out, const MlpAdam *madam, uint32_t n_rays, uint32_t B,
+                            const naf_render_cfg *cfg, hipStream_t s) {
+    const bool with_loss = loss.target != nullptr;
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
         {
             const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
             const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
             if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
             // fewer rays than the chip has SIMDs (1 024): up to 8 tile ranges per ray, never more ranges than tiles, so that every
-            // SIMD gets a wave (from one wave per SIMD on, more items only mean more slabs to fold: measured at 1 024 rays)
+            // SIMD gets a wave; NAF_CFG_BACKWARD_SPLIT_2X (diagnostic) goes on to two waves per SIMD
             const uint32_t tiles = (cfg->n_samples + 15u) / 16u;
+            const uint64_t wave_goal = (cfg->flags & NAF_CFG_BACKWARD_SPLIT_2X) != 0u ? 2048u : 1024u;
             uint32_t log2_parts = 0;
-            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= 1024u && (2u << log2_parts) <= tiles) ++log2_parts;
+            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= wave_goal && (2u << log2_parts) <= tiles) ++log2_parts;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((((uint64_t)n_rays << log2_parts) + 3) / 4, kBackwardBlocks16));
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
-                               grad_acc, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation, log2_parts); }
+                               grad_acc, loss, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation, log2_parts); }
             if (int rc = check_launch("mlp16_backward_kernel")) return rc;
-            { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + kReduceParams - 1) / kReduceParams), dim3(256), 0, s, slabs, grid16, grad_mlp); }
-            return check_launch("mlp_grad_reduce_kernel");
+            return run_mlp_grad_reduce(slabs, grid16, grad_mlp, loss_out, with_loss, madam, s);
         }
     }
     auto kern = mlp_backward_kernel<P, C>;
@@ -1102,11 +1117,10 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     if (int rc = raise_lds_limit(kern, lds, "mlp_backward_kernel: cannot raise dynamic LDS limit")) return rc;      // fp32 images need > 64 KiB
     if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
-    { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc,
+    { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc, loss,
                        (typename P::feat_t::store_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
-    { ProfScope prof_("mlp_grad_reduce_kernel", s); hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kMlpParams + kReduceParams - 1) / kReduceParams), dim3(256), 0, s, slabs, grid, grad_mlp); }
-    return check_launch("mlp_grad_reduce_kernel");
+    return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, s);
 }
 
 // Workgroups a reducer launch over `nl` levels splits each bucket's tiles between: 1 when buckets x levels already fill the chip
@@ -1300,7 +1314,8 @@ template <typename P, uint32_t C>
 static int render_backward_impl(const float *rays, const float *t_rand, const float *grad_acc, const void *emb, const int32_t *offsets,
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
                                 void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
-                                const AdamTail *adam = nullptr, bool from_train = false) {
+                                const AdamTail *adam = nullptr, bool from_train = false, const LossInputs &loss = LossInputs{nullptr, nullptr, nullptr},
+                                float *loss_out = nullptr, const MlpAdam *madam = nullptr) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
@@ -1313,7 +1328,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     // (a fused forward of the same cfg left no features behind unless it was asked to store them)
     if (!features_valid || (forward_fused(cfg) && (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) == 0u && !from_train))
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, n_rays, B, cfg, s)) return rc;
+    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, loss, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, loss_out, madam, n_rays, B, cfg, s)) return rc;
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
@@ -1324,18 +1339,13 @@ template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr) {
+                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true)) return rc;
-    const Workspace w = carve(ws, cfg, (uint64_t)n_rays * cfg->n_samples);
-    {   // the partial sums live behind grad_acc in the workspace (carve reserves 256 bytes for them)
-        float *partial = w.grad_acc + (((size_t)n_rays + 63) & ~(size_t)63);
-        const uint32_t blocks = n_rays >= 16384u ? kLossBlocks : 1u;
-        ProfScope prof_("loss_grad_kernel", s);
-        hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(1024), 0, s, acc, target, ray_weight, w.grad_acc, loss_out, partial, n_rays);
-        if (blocks > 1u && loss_out != nullptr) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, blocks, loss_out);
-    }
-    if (int rc = check_launch("loss_grad_kernel")) return rc;
-    return render_backward_impl<P, C>(rays, t_rand, w.grad_acc, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true);
+    // the masked squared error and its gradient are formed inside the backward kernel (LossInputs); the loss reaches loss_out (+=)
+    // through the slab reduction that also finishes the MLP gradient
+    const LossInputs loss{acc, target, ray_weight};
+    return render_backward_impl<P, C>(rays, t_rand, nullptr, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true,
+                                      loss, loss_out, madam);
 }
 
 template <typename P, uint32_t C>
@@ -1476,7 +1486,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream,
-                              const AdamTail *adam = nullptr) {
+                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
@@ -1494,7 +1504,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
         return NAF_OK;
     }
     NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam);
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
@@ -1532,13 +1542,22 @@ extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, con
     tail.param = adam->param; tail.m = adam->exp_avg; tail.v = adam->exp_avg_sq;
     tail.lp = adam->param_lp; tail.lp_dtype = adam->lp_dtype; tail.overflow = nullptr;
     tail.a = make_adam_args(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale);
+    // the MLP's own update rides on the slab reduction when the caller hands over its state (an empty batch still has to step it)
+    MlpAdam madam{adam->mlp_param, adam->mlp_exp_avg, adam->mlp_exp_avg_sq, tail.a};
+    const MlpAdam *mp = nullptr;
+    if (adam->mlp_param != nullptr) {
+        if (!adam->mlp_exp_avg || !adam->mlp_exp_avg_sq || !grad_mlp) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null MLP optimiser state");
+        if (adam->mlp_param != mlp) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: mlp_param must be the parameter block the step reads (`mlp`)");
+        if (n_rays != 0) mp = &madam;
+        else if (int rc = launch_adam(adam->mlp_param, adam->mlp_exp_avg, adam->mlp_exp_avg_sq, grad_mlp, nullptr, 0, NAF_MLP_PARAMS, tail.a, true, (hipStream_t)stream)) return rc;
+    }
     const uint64_t n_points = (uint64_t)n_rays * cfg->n_samples;
     if (n_rays != 0 && workspace != nullptr && n_points < (1ull << 31) && adam_tail_possible(cfg, carve(workspace, cfg, n_points)))
         return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                  n_rays, cfg, workspace, nullptr, stream, &tail);
+                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp);
     // small batches (atomic scatter), split reducer launches, per-level diagnostics, empty batches: the two passes one after the other
     if (int rc = render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                    n_rays, cfg, workspace, nullptr, stream)) return rc;
+                                    n_rays, cfg, workspace, nullptr, stream, nullptr, mp)) return rc;
     return launch_adam(adam->param, adam->exp_avg, adam->exp_avg_sq, grad_embeddings, adam->param_lp, adam->lp_dtype, adam->n, tail.a,
                        true, (hipStream_t)stream);
 }

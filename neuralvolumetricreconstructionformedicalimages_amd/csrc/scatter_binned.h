@@ -406,6 +406,29 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     // accumulators are channel-major, acc[ch][local row]: the two 8-byte cells of a row would otherwise sit 8 bytes apart and
     // one ds_add_u64 instruction (one channel of 64 rows) could reach only every other bank pair
     const uint32_t pitch = plan.max_local_rows;
+    // kAdam: the parameters and moments of this workgroup's rows are requested NOW, before the records are streamed.  The update at
+    // the end is pure streaming (26 bytes per table element, the fixed cost of a step whatever its batch), the record phase in
+    // between is latency-bound at small batches: issued here, the two overlap instead of following each other (1 024-ray step:
+    // 0.131 -> see DESIGN.md 4.2).  rows_local * C <= 16 * 1024 by the LDS bound of the plan (make_bin_plan); whatever lies beyond is
+    // loaded in the tail as before.
+    constexpr uint32_t kPre = (kAdam && C <= 2u) ? 16u : 0u;
+    float pre_p[kPre ? kPre : 1u], pre_m[kPre ? kPre : 1u], pre_v[kPre ? kPre : 1u];
+    if constexpr (kPre != 0u) {
+        const float *__restrict__ pp = adam.param + (size_t)off * C;
+        const float *__restrict__ pm = adam.m + (size_t)off * C;
+        const float *__restrict__ pv = adam.v + (size_t)off * C;
+#pragma unroll
+        for (uint32_t k = 0; k < kPre; ++k) {
+            const uint32_t i = threadIdx.x + k * T_;
+            const uint32_t local = i / C, ch = i - local * C;
+            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            pre_p[k] = pre_m[k] = pre_v[k] = 0.0f;
+            if (i < rows_local * C && row < T) {
+                const size_t e = (size_t)row * C + ch;
+                pre_p[k] = pp[e]; pre_m[k] = pm[e]; pre_v[k] = pv[e];
+            }
+        }
+    }
     for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
     __syncthreads();
 
@@ -522,25 +545,37 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
         float *__restrict__ pp = adam.param + (size_t)off * C;
         float *__restrict__ pm = adam.m + (size_t)off * C;
         float *__restrict__ pv = adam.v + (size_t)off * C;
+        auto update = [&](uint32_t local, uint32_t ch, uint32_t row, float p, float m, float v) {
+            const size_t e = (size_t)row * C + ch;
+            float g = poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
+            if (spilled) {
+                const float extra = gg[e];
+                if (extra != 0.0f) { g = extra + g; gg[e] = 0.0f; }          // the order of the separate route: table += sum
+            }
+            adam_one(p, m, v, g, adam.a);
+            pp[e] = p; pm[e] = m; pv[e] = v;
+            if (adam.lp != nullptr) {
+                const size_t el = (size_t)off * C + e;
+                if (adam.lp_dtype == kAdamLpF16) reinterpret_cast<_Float16 *>(adam.lp)[el] = (_Float16)p;
+                else reinterpret_cast<uint16_t *>(adam.lp)[el] = f32_to_bf16(p);
+            }
+        };
+        if constexpr (kPre != 0u) {
+#pragma unroll
+            for (uint32_t k = 0; k < kPre; ++k) {
+                const uint32_t i = threadIdx.x + k * T_;
+                const uint32_t local = i / C, ch = i - local * C;
+                const uint32_t row = row_of(bucket, local, plan.log2_nb);
+                if (i < rows_local * C && row < T) update(local, ch, row, pre_p[k], pre_m[k], pre_v[k]);
+            }
+        }
 #pragma unroll 4
-        for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
+        for (uint32_t i = threadIdx.x + kPre * T_; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
             const uint32_t row = row_of(bucket, local, plan.log2_nb);
             if (row < T) {
                 const size_t e = (size_t)row * C + ch;
-                float g = poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
-                if (spilled) {
-                    const float extra = gg[e];
-                    if (extra != 0.0f) { g = extra + g; gg[e] = 0.0f; }          // the order of the separate route: table += sum
-                }
-                float p = pp[e], m = pm[e], v = pv[e];
-                adam_one(p, m, v, g, adam.a);
-                pp[e] = p; pm[e] = m; pv[e] = v;
-                if (adam.lp != nullptr) {
-                    const size_t el = (size_t)off * C + e;
-                    if (adam.lp_dtype == kAdamLpF16) reinterpret_cast<_Float16 *>(adam.lp)[el] = (_Float16)p;
-                    else reinterpret_cast<uint16_t *>(adam.lp)[el] = f32_to_bf16(p);
-                }
+                update(local, ch, row, pp[e], pm[e], pv[e]);
             }
         }
     } else if (gridDim.z == 1u) {

@@ -60,17 +60,16 @@ def global_mean_weights(mask, group=None):
 
 
 def default_bucket_levels(num_levels):
-    """Level ranges in the order the gradient scatter finishes them: the fine half, the next quarter, the coarse quarter.
-    Every reducer launch still runs in full rounds of 256 workgroups (64 row buckets x 8 levels = 512; the two launches of
-    four levels split each bucket's tiles four ways, 4 x 256, and finish their rows with one atomic each),
-    each bucket's all-reduce hides behind the reduction of the buckets after it, and the exchange left exposed at the end is
-    the coarse quarter, whose dense levels are small (6.7 of 57 MB at L = 16, T = 2^19; 33.6 and 16.8 MB before it).
-    Measured on one GPU (bench.py --force-dp --buckets ...): 9.08-9.18 ms per step against 9.13-9.15 ms for two halves -- the
-    reducer itself is faster when the coarse levels, whose runs are uneven, do not share a launch with four hashed levels
-    (2.05 against 2.14 ms) -- with a last bucket a third the size."""
+    """Level ranges in the order the gradient scatter finishes them: the fine half, then the coarse half.
+    Two buckets of L/2 levels keep every reducer launch UNSPLIT (64 row buckets x 8 levels = 512 workgroups: a workgroup is the
+    sole owner of its rows and adds its 64-bit fixed-point sums in a fixed order), so the table gradient a rank hands to the
+    exchange is bit-reproducible from run to run.  Buckets of four levels or fewer (round 2's default had two of them) split each
+    row bucket's tiles over several workgroups that finish with fp32 atomics -- 6.7 MB instead of 22.5 MB left exposed behind the
+    last reduction, at the price of run-to-run noise in the last bits; they remain available through `bucket_levels`.  With the
+    reduce-scatter / sharded-Adam / all-gather form of the exchange the tail that cannot overlap is a quarter of what the
+    all-reduce left anyway.  Measured on one GPU (bench.py --force-dp --buckets ...): 9.13-9.15 ms per 65 536-ray step for the
+    two halves against 9.08-9.18 ms for three buckets."""
     L = int(num_levels)
-    if L >= 4:
-        return [(L // 2, L), (L // 4, L // 2), (0, L // 4)]
     return [(L // 2, L), (0, L // 2)] if L >= 2 else [(0, L)]
 
 
@@ -108,6 +107,26 @@ def aligned_update_slices(slices, multiple=4):
     bounds.append(tiled[-1][1])
     moved = {rng: (bounds[i], bounds[i + 1]) for i, rng in enumerate(tiled)}
     return [moved[rng] for rng in slices]
+
+
+def sharded_exchange_slices(slices, world, padded_end):
+    """Exchange ranges for the reduce-scatter / all-gather form of the step: the bucket ranges `slices` (in the order their
+    gradients become final) with every boundary moved to a multiple of world * 4 elements -- in favour of the bucket that
+    finishes LATER, whose collective may touch the ragged elements because they are final by then -- and the table's end
+    extended to `padded_end` (the flat buffers are padded to a multiple of lcm(64, world * 4) elements).  Every range then
+    splits into `world` equal shards that start on 16-byte boundaries."""
+    unit = 4 * int(world)
+    if padded_end % unit:
+        raise ValueError("padded_end must be a multiple of world * 4 elements")
+    last = max(slices, key=lambda r: r[1])
+    if padded_end < last[1]:
+        raise ValueError("padded_end lies inside the table")
+    stretched = [(a, padded_end) if (a, b) == last else (a, b) for a, b in slices]
+    out = aligned_update_slices(stretched, multiple=unit)
+    for a, b in out:
+        if (b - a) % unit or b <= a:
+            raise ValueError(f"bucket range [{a}, {b}) cannot be split into {world} aligned shards")
+    return out
 
 
 def all_reduce_buckets_(flat, slices, group=None):

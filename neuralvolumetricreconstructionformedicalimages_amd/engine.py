@@ -14,6 +14,7 @@ Replaces, for the canonical NAF network, what reference src/trainer.py:134-142 +
 from __future__ import annotations
 
 import ctypes
+import math
 
 import torch
 
@@ -24,7 +25,7 @@ from . import fused
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
                  mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384, scatter_mode=None, cfg_flags=None,
-                 bucket_levels=None, fuse_table_adam=True):
+                 bucket_levels=None, fuse_table_adam=True, dp_mode="sharded"):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -39,13 +40,27 @@ class NAFEngine:
         self.step_count = 0
         self.rays_seen = 0
         self.process_group = process_group
+        if dp_mode not in ("sharded", "allreduce"):
+            raise ValueError("dp_mode must be 'sharded' (reduce-scatter, per-rank Adam on a table slice, all-gather) or 'allreduce'")
+        self.dp_mode = dp_mode
+        self.world, self.rank = 1, 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.scatter_mode, self.cfg_flags = scatter_mode, cfg_flags     # None: fused.scatter_mode() default (auto)
         # single-GPU, single-stream steps let the gradient reducer apply the table's Adam update itself (naf_render_train_adam:
         # the gradient table is neither written, re-read nor cleared; bit-identical to backward() + optimizer_step())
         self.fuse_table_adam = bool(fuse_table_adam)
 
         # ---- flat fp32 master parameters; module parameters become views ---------------------------------
-        self.emb = enc.embeddings.data.float().contiguous()
+        # The table lives in a flat buffer whose length is rounded up to `pad_to` elements: the exchange ranges of a data-parallel
+        # step are multiples of world * 4 elements (equal 16-byte-aligned shards per rank), the last one reaches into the padding.
+        n_emb = enc.embeddings.numel()
+        self._pad_to = 64 * self.world // math.gcd(64, 4 * self.world) * 4 if self.world > 1 else 64
+        n_pad = (n_emb + self._pad_to - 1) // self._pad_to * self._pad_to
+        self._emb_flat = torch.zeros(n_pad, device=dev)
+        self._emb_flat[:n_emb] = enc.embeddings.data.float().reshape(-1)
+        self.emb = self._emb_flat[:n_emb].view(enc.embeddings.shape)
         enc.embeddings.data = self.emb
         self.mlp = net.packed_mlp().detach().clone().contiguous()
         off = 0
@@ -56,13 +71,14 @@ class NAFEngine:
                 off += n
         assert off == _abi.MLP_PARAMS
         self.table_dtype = table_dtype
-        self.emb_lp = None if table_dtype == torch.float32 else self.emb.to(table_dtype)
+        self._lp_flat = None if table_dtype == torch.float32 else self._emb_flat.to(table_dtype)
+        self.emb_lp = None if self._lp_flat is None else self._lp_flat[:n_emb].view(self.emb.shape)
         self.emb_m, self.emb_v = (torch.zeros_like(self.emb) for _ in range(2))
         self.mlp_m, self.mlp_v = (torch.zeros_like(self.mlp) for _ in range(2))
         # table gradient | MLP gradient | loss in ONE flat buffer (sections 256-byte aligned): a data-parallel step is a
         # single all-reduce
-        n_emb, n_mlp = self.emb.numel(), self.mlp.numel()
-        o_mlp = (n_emb + 63) // 64 * 64
+        n_mlp = self.mlp.numel()
+        o_mlp = n_pad
         o_loss = o_mlp + (n_mlp + 63) // 64 * 64
         self.grad_flat = torch.zeros(o_loss + 64, device=dev)
         self.emb_g = self.grad_flat[:n_emb].view(self.emb.shape)
@@ -101,7 +117,7 @@ class NAFEngine:
         if len(bucket_levels) > _abi.MAX_GRAD_BUCKETS:
             raise ValueError(f"at most {_abi.MAX_GRAD_BUCKETS} gradient buckets")
         n_emb = self.emb.numel()
-        o_mlp = (n_emb + 63) // 64 * 64
+        o_mlp = self._emb_flat.numel()
         dp = {"levels": bucket_levels, "comm": torch.cuda.Stream(device=self.device), "time": False, "timings": []}
         # torch creates the underlying hipEvent_t at the first record(): do that now so the handles can be handed to the library
         def event():
@@ -115,6 +131,17 @@ class NAFEngine:
         dp["slices"] = naf_dist.grad_bucket_slices(self.offsets.tolist(), self.net.encoder.level_dim, bucket_levels)
         dp["update_slices"] = naf_dist.aligned_update_slices(dp["slices"])              # Adam works on 16-byte groups
         dp["mlp_slice"] = (o_mlp, self.grad_flat.numel())                              # MLP gradient + loss cell
+        if self.dp_mode == "sharded":
+            # reduce-scatter -> Adam on this rank's slice of every bucket -> all-gather of the updated table:
+            # exchange ranges are multiples of world * 4 elements (boundaries moved in favour of the bucket that finishes later,
+            # the table's end extended into the buffer's padding), so every rank owns an equal, 16-byte-aligned shard of each
+            dp["shard_slices"] = naf_dist.sharded_exchange_slices(dp["slices"], self.world, o_mlp)
+            longest = max((b - a) // self.world for a, b in dp["shard_slices"])
+            dp["shard_grad"] = [torch.zeros(longest, device=self.device) for _ in bucket_levels]      # reduce-scatter outputs
+            dp["rs_done"] = [event() for _ in bucket_levels]
+            dp["adam_done"] = [event() for _ in bucket_levels]
+            dp["gathered"] = event()
+            dp["master_stale"] = False
         st = _abi.GradBuckets()
         st.n_buckets = len(bucket_levels)
         for i, (a, b) in enumerate(bucket_levels):
@@ -293,6 +320,101 @@ class NAFEngine:
             c1.record(main)
             dp["timings"].append((marks, c0, waited, c1))
 
+    def _exchange_and_step_sharded(self):
+        """Data-parallel tail with a sharded optimiser (ZeRO-1 style).  Per bucket, in the order the scatter finishes
+        them: reduce-scatter of its gradient range on the side stream (each rank receives the SUM over ranks of its 1/N slice:
+        (N-1)/N x 57 MB on the wire instead of twice that for an all-reduce) -> Adam on exactly that slice of parameter and moments
+        on the main stream (1/N of the optimiser pass; the other slices' moments are never touched here) -> all-gather of the
+        updated slice of the table the kernels read (the 16-bit shadow in 16-bit mode: (N-1)/N x 28.5 MB; the fp32 table itself
+        in parity mode).  The fp32 master of the slices other ranks own is refreshed only on demand (`gather_state`, before an
+        evaluation or a checkpoint).  The MLP gradient + loss (17 KB) are all-reduced and stepped on every rank."""
+        import torch.distributed as dist
+        dp = self._dp
+        main, comm = torch.cuda.current_stream(self.device), dp["comm"]
+        timing = dp["time"]
+        marks = []
+        world, rank, n_emb = self.world, self.rank, self.emb.numel()
+        grp = self.process_group
+
+        def mark(stream):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            return ev
+
+        with torch.cuda.stream(comm):
+            comm.wait_event(dp["mlp_ready"])
+            t0 = mark(comm) if timing else None
+            a, b = dp["mlp_slice"]
+            dist.all_reduce(self.grad_flat[a:b], group=grp)
+            dp["mlp_done"].record(comm)
+            if timing:
+                marks.append((t0, mark(comm)))
+            for i, (a, b) in enumerate(dp["shard_slices"]):
+                comm.wait_event(dp["ready"][i])
+                t0 = mark(comm) if timing else None
+                sh = (b - a) // world
+                dist.reduce_scatter_tensor(dp["shard_grad"][i][:sh], self.grad_flat[a:b], group=grp)
+                self.grad_flat[a:b].zero_()                  # the next step's scatter accumulates from zero
+                dp["rs_done"][i].record(comm)
+                if timing:
+                    marks.append((t0, mark(comm)))
+        c0 = mark(main) if timing else None                  # end of this rank's own compute
+        self.step_count += 1
+        lp_code = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
+        emb, m, v = (t.view(-1) for t in (self.emb, self.emb_m, self.emb_v))
+        read_flat = self._emb_flat if self._lp_flat is None else self._lp_flat      # what the kernels gather from
+        waited = []
+        for i, (a, b) in enumerate(dp["shard_slices"]):
+            sh = (b - a) // world
+            lo = a + rank * sh
+            hi = min(lo + sh, n_emb)                         # the last shard of the last range reaches into the padding
+            main.wait_event(dp["rs_done"][i])
+            if timing:
+                waited.append(mark(main))
+            if hi > lo:
+                lp = None if self._lp_flat is None else self._lp_flat[lo:hi]
+                self._adam(emb[lo:hi], m[lo:hi], v[lo:hi], dp["shard_grad"][i][:hi - lo], lp, lp_code, "adam_step(table shard)")
+            dp["adam_done"][i].record(main)
+        main.wait_event(dp["mlp_done"])
+        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
+        with torch.cuda.stream(comm):
+            for i, (a, b) in enumerate(dp["shard_slices"]):
+                sh = (b - a) // world
+                comm.wait_event(dp["adam_done"][i])
+                t0 = mark(comm) if timing else None
+                mine = read_flat[a + rank * sh:a + (rank + 1) * sh].clone()      # out of place: no aliasing assumptions on the backend
+                dist.all_gather_into_tensor(read_flat[a:b], mine, group=grp)
+                if timing:
+                    marks.append((t0, mark(comm)))
+            dp["gathered"].record(comm)
+        main.wait_event(dp["gathered"])                       # the next forward reads the gathered table
+        dp["master_stale"] = self._lp_flat is not None and world > 1
+        if timing:
+            dp["timings"].append((marks, c0, waited, mark(main)))
+
+    def gather_state(self):
+        """Sharded data-parallel training keeps the fp32 master (16-bit mode) and the Adam moments current only on the rank that
+        owns a slice.  Collective: every rank calls it (before an evaluation or a checkpoint, trainer.py:113-126) and ends up
+        with the complete master table and moments.  A no-op for single-process and all-reduce training."""
+        if self._dp is None or self.dp_mode != "sharded" or self.world == 1:
+            return
+        import torch.distributed as dist
+        dp = self._dp
+        torch.cuda.current_stream(self.device).wait_event(dp["gathered"])
+        n_emb, world, rank = self.emb.numel(), self.world, self.rank
+        full = [self.emb_m.view(-1), self.emb_v.view(-1)] + ([self.emb.view(-1)] if self._lp_flat is not None else [])
+        for a, b in dp["shard_slices"]:
+            sh = (b - a) // world
+            lo = a + rank * sh
+            for t in full:
+                mine = torch.zeros(sh, device=self.device)
+                k = max(0, min(lo + sh, n_emb) - lo)
+                mine[:k] = t[lo:lo + k]
+                out = torch.empty(b - a, device=self.device)
+                dist.all_gather_into_tensor(out, mine, group=self.process_group)
+                t[a:min(b, n_emb)] = out[:min(b, n_emb) - a]
+        dp["master_stale"] = False
+
     def comm_timing(self, enable=True):
         """Switch on event timing of the exchange (bench.py); `comm_report()` then returns per-step averages."""
         if self._dp is not None:
@@ -318,7 +440,9 @@ class NAFEngine:
             self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
         else:
             self.backward(rays, target, weight, t_rand, ray_base)
-            if self._dp is not None:
+            if self._dp is not None and self.dp_mode == "sharded":
+                self._exchange_and_step_sharded()
+            elif self._dp is not None:
                 self._exchange_and_step()
             else:
                 self.optimizer_step()
@@ -326,8 +450,8 @@ class NAFEngine:
         return self.loss
 
     def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base):
-        """backward() + optimizer_step() in two library calls: naf_render_train_adam (the reducer finishes every table row with
-        its Adam update) and the Adam pass over the 4 225 MLP parameters."""
+        """backward() + optimizer_step() in ONE library call: naf_render_train_adam -- the gradient reducer finishes every table
+        row with its Adam update, the slab reduction of the MLP gradient does the same for the 4 225 MLP parameters."""
         n = rays.shape[0]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
@@ -341,12 +465,12 @@ class NAFEngine:
         st.param_lp = None if self.emb_lp is None else self.emb_lp.data_ptr()
         st.lp_dtype = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
         st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = self.emb.numel(), self.lr, b1, b2, self.eps, self.step_count, 1.0
+        st.mlp_param, st.mlp_exp_avg, st.mlp_exp_avg_sq = self.mlp.data_ptr(), self.mlp_m.data_ptr(), self.mlp_v.data_ptr()
         _abi.check(_abi.lib().naf_render_train_adam(
             _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
             _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
             ctypes.byref(cfg), _abi.ptr(ws), ctypes.byref(st), _abi.stream_ptr()), "render_train_adam")
-        fused._bump(self.device)
-        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
+        fused._bump(self.device)                               # (the MLP's update rode on the slab reduction of that call)
 
     # ---- optimiser state in torch.optim.Adam's layout (checkpoint compatibility, trainer.py:118-126) ---------
     def optimizer_state_dict(self):

@@ -209,10 +209,12 @@ def render_samples(rays, net, n_samples, perturb, t_rand=None, seed=0, mlp_preci
     sigma = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_sigma else None
     depth = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32) if want_depth else None
     enc = net.encoder
+    # every tensor behind a pointer stays referenced until the launch has been issued (a temporary would go back to the caching
+    # allocator at once and could be handed to an allocation that is enqueued before the kernel)
+    emb, mlp, offs = enc.embeddings.detach().contiguous(), net.packed_mlp().contiguous(), _offsets(enc, rays.device)
     _abi.check(_abi.lib().naf_render_forward_samples(
-        _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(enc.embeddings.detach().contiguous()), _abi.ptr(_offsets(enc, rays.device)),
-        _abi.ptr(net.packed_mlp().contiguous()), _abi.ptr(acc), _abi.ptr(sigma), _abi.ptr(depth), n, ctypes.byref(cfg), _abi.ptr(ws),
-        _abi.stream_ptr()), "render_forward_samples")
+        _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(emb), _abi.ptr(offs), _abi.ptr(mlp), _abi.ptr(acc), _abi.ptr(sigma), _abi.ptr(depth),
+        n, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_forward_samples")
     _bump(rays.device)
     return acc, sigma, depth
 
@@ -233,9 +235,9 @@ def field_query_grid(net, starts, stops, dims, mlp_precision=None, workspace_cap
     ws = forward_workspace(cfg, B, device, workspace_cap)
     sigma = torch.empty(dims, device=device, dtype=torch.float32)
     a, b, d = (ctypes.c_double * 3)(*[float(v) for v in starts]), (ctypes.c_double * 3)(*[float(v) for v in stops]), (ctypes.c_uint32 * 3)(*dims)
-    _abi.check(_abi.lib().naf_field_forward_grid(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), _abi.ptr(enc.embeddings.detach().contiguous()),
-                                                 _abi.ptr(_offsets(enc, device)), _abi.ptr(net.packed_mlp().contiguous()), _abi.ptr(sigma),
-                                                 ctypes.byref(cfg), _abi.ptr(ws), ws.numel(), _abi.stream_ptr()), "field_forward_grid")
+    emb, mlp, offs = enc.embeddings.detach().contiguous(), net.packed_mlp().contiguous(), _offsets(enc, device)
+    _abi.check(_abi.lib().naf_field_forward_grid(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), _abi.ptr(emb), _abi.ptr(offs), _abi.ptr(mlp),
+                                                 _abi.ptr(sigma), ctypes.byref(cfg), _abi.ptr(ws), ws.numel(), _abi.stream_ptr()), "field_forward_grid")
     _bump(device)
     return sigma
 

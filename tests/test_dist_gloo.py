@@ -102,10 +102,88 @@ def test_bucketed_exchange_equals_single_all_reduce():
         assert p.exitcode == 0
     for rank, table_ok, mlp_ok, slices, buckets in results:
         assert table_ok and mlp_ok
-        assert buckets == [(8, 16), (4, 8), (0, 4)]                  # fine levels first: their exchange hides behind the coarser ones
-        assert slices[2][0] == 0 and slices[2][1] == slices[1][0] and slices[1][1] == slices[0][0]    # the slices tile the table exactly once
+        assert buckets == [(8, 16), (0, 8)]                          # fine half first (its exchange hides behind the coarse half's
+        #                                                              reduction); halves keep every reducer launch unsplit = deterministic
+        assert slices[1][0] == 0 and slices[1][1] == slices[0][0]    # the slices tile the table exactly once
     with np.testing.assert_raises(ValueError):
         dist.grad_bucket_slices([0, 10, 20, 30], 2, [(0, 2), (1, 3)])           # overlap
     with np.testing.assert_raises(ValueError):
         dist.grad_bucket_slices([0, 10, 20, 30], 2, [(0, 2)])                   # level 2 missing
     assert dist.grad_bucket_slices([0, 10, 20, 30], 2, [(2, 3), (0, 2)]) == [(40, 60), (0, 40)]
+
+
+# ---- sharded optimiser: reduce-scatter -> Adam on the rank's slice -> all-gather (engine._exchange_and_step_sharded) -----------
+def _adam_ref(p, m, v, g, step, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    _, _, _, group = dist.init_from_env(device_type="cpu")
+    from neuralvolumetricreconstructionformedicalimages_amd.encoder import level_offsets
+    offs = level_offsets(3, 16, 16, 12)
+    C = 2
+    n_emb = int(offs[-1]) * C
+    import math
+    pad_to = 64 * 4 * world // math.gcd(64, 4 * world)              # the engine's padding rule: lcm(64, 4 * world)
+    n_pad = (n_emb + pad_to - 1) // pad_to * pad_to
+    slices = dist.grad_bucket_slices(offs, C, [(11, 16), (3, 11), (0, 3)])
+    ranges = dist.sharded_exchange_slices(slices, world, n_pad)
+    g0 = torch.Generator().manual_seed(7)
+    p_ref = torch.randn(n_emb, generator=g0)
+    p = torch.zeros(n_pad)
+    p[:n_emb] = p_ref
+    m, v = torch.zeros(n_emb), torch.zeros(n_emb)
+    m_ref, v_ref = torch.zeros(n_emb), torch.zeros(n_emb)
+    for step in (1, 2, 3):
+        grad = torch.zeros(n_pad)
+        grad[:n_emb] = torch.randn(n_emb, generator=torch.Generator().manual_seed(1000 * step + rank))
+        whole = grad.clone()
+        td.all_reduce(whole, group=group)
+        _adam_ref(p_ref, m_ref, v_ref, whole[:n_emb], step)        # the all-reduce form, every rank the whole table
+        for a, b in ranges:                                        # the sharded form
+            sh = (b - a) // world
+            out = torch.zeros(sh)
+            td.reduce_scatter_tensor(out, grad[a:b].contiguous(), group=group)
+            lo = a + rank * sh
+            hi = min(lo + sh, n_emb)
+            if hi > lo:
+                _adam_ref(p[lo:hi], m[lo:hi], v[lo:hi], out[:hi - lo], step)
+            td.all_gather_into_tensor(p[a:b], p[lo:lo + sh].clone(), group=group)
+    owned = torch.zeros(n_emb, dtype=torch.bool)
+    for a, b in ranges:
+        sh = (b - a) // world
+        owned[a + rank * sh:min(a + (rank + 1) * sh, n_emb)] = True
+    exact = world == 2                                             # a sum of three addends depends on the order the backend takes them in
+    same_p = torch.equal(p[:n_emb], p_ref) if exact else torch.allclose(p[:n_emb], p_ref, rtol=0, atol=2e-4)   # Adam steps of lr = 1e-2
+    same_m = torch.equal(m[owned], m_ref[owned]) if exact else torch.allclose(m[owned], m_ref[owned], rtol=1e-5, atol=1e-6)
+    q.put((rank, bool(same_p), bool(same_m), float(owned.float().mean()), ranges, n_pad))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def _run_sharded(world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = collect(procs, q, len(procs), timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def test_sharded_optimizer_exchange_equals_all_reduce_then_adam():
+    """reduce-scatter -> per-rank Adam on a 1/N slice -> all-gather leaves every rank with the parameters of all-reduce -> Adam
+    on the whole table -- bit for bit with 2 ranks (a sum of two addends has one order), to rounding with 3 (a world size
+    that does not divide the buffer's 64-element granule: the padding rule is lcm(64, 4 * world))."""
+    for world, port in ((2, 33500 + (os.getpid() % 1000)), (3, 35500 + (os.getpid() % 1000))):
+        for rank, params_equal, moments_equal, share, ranges, n_pad in _run_sharded(world, port):
+            assert params_equal and moments_equal
+            assert abs(share - 1.0 / world) < 0.01                   # every rank steps 1/N of the table
+            assert ranges[-1][0] == 0 and max(b for _, b in ranges) == n_pad
+            assert all((b - a) % (4 * world) == 0 and a % 4 == 0 for a, b in ranges)

@@ -32,7 +32,10 @@ def _batch(n=256, S=64):
     return rays, torch.rand(n, S, generator=g), torch.rand(n, generator=g) * 0.3, torch.rand(n, generator=g) > 0.2
 
 
-def _worker(rank, world, port, out):
+_TABLES = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _worker(rank, world, port, out, dp_mode, table):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as td
     from neuralvolumetricreconstructionformedicalimages_amd import dist
@@ -41,26 +44,31 @@ def _worker(rank, world, port, out):
     group = td.group.WORLD
     net = _make(seed=0 if rank == 0 else 99)                      # rank 1 starts different until the broadcast
     S = 64
-    engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=group)
-    dist.broadcast_parameters([engine.emb, engine.mlp], group)
+    engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=group, dp_mode=dp_mode, table_dtype=_TABLES[table])
+    engine.broadcast_parameters()
     rays, t_rand, target, mask = _batch(S=S)
     b, e = dist.shard_range(rays.shape[0], rank, world)
     for _ in range(3):
         w = dist.global_mean_weights(mask[b:e].cuda(), group)
         engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, t_rand=t_rand[b:e].cuda().contiguous())
+    read = engine.table.float().cpu().numpy()                     # what the next forward would gather from (all-gathered)
+    engine.gather_state()                                         # collective: complete fp32 master + moments on every rank
     torch.cuda.synchronize()
-    out.put((rank, engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item())))
+    out.put((rank, engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item()), read, engine.emb_m.cpu().numpy()))
     td.barrier()
     td.destroy_process_group()
 
 
-def test_two_rank_training_equals_single_process():
+@pytest.mark.parametrize("dp_mode,table", [("sharded", "fp32"), ("sharded", "bf16"), ("allreduce", "fp32"), ("allreduce", "bf16")])
+def test_two_rank_training_equals_single_process(dp_mode, table):
+    """Two ranks (gloo, sharing the test box's GPU) against one process on the concatenated batch, for both forms of the
+    exchange: all-reduce + replicated Adam, and reduce-scatter -> Adam on the rank's table slice -> all-gather (sharded)."""
     from neuralvolumetricreconstructionformedicalimages_amd import dist
     from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, dp_mode, table)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(collect(procs, q, len(procs)), key=lambda t: t[0])
@@ -70,17 +78,21 @@ def test_two_rank_training_equals_single_process():
 
     net = _make(seed=0)
     S = 64
-    engine = NAFEngine(net, S, perturb=True, lr=1e-2)
+    engine = NAFEngine(net, S, perturb=True, lr=1e-2, table_dtype=_TABLES[table])
     rays, t_rand, target, mask = _batch(S=S)
     for _ in range(3):
         w = dist.global_mean_weights(mask.cuda(), None)
         engine.train_step(rays.cuda(), target.cuda(), w, t_rand=t_rand.cuda())
     emb, mlp, loss = engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item())
-    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])    # replicas agree
+    for k in (1, 2, 4, 5):                                        # replicas agree: master, MLP, the table they read, moments
+        assert np.array_equal(results[0][k], results[1][k]), k
+    # the table the kernels read is the (rounded) master everywhere, also for the slices another rank stepped
+    assert np.array_equal(results[0][4], torch.from_numpy(results[0][1]).to(_TABLES[table]).float().numpy())
     # Adam steps of +-lr amplify rounding of near-zero gradients, hence the absolute tolerance of a fraction of lr
     np.testing.assert_allclose(results[0][2], mlp, rtol=0, atol=2e-4)
     assert np.mean(np.abs(results[0][1] - emb) > 2e-3) < 1e-3
     np.testing.assert_allclose(results[0][3], loss, rtol=1e-3)
+    assert np.mean(np.abs(results[0][5] - engine.emb_m.cpu().numpy()) > 1e-5 * max(1e-12, float(np.abs(results[0][5]).max())) + 1e-9) < 1e-2
 
 
 def _empty_shard_worker(rank, world, port, out):
@@ -141,10 +153,12 @@ def _rccl_worker(port, out):
     td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     group = td.group.WORLD
     res = {}
-    for tag, pg, buckets in (("single", None, None), ("dp", group, None), ("dp3", group, [(11, 16), (3, 11), (0, 3)])):
+    for tag, pg, buckets, mode in (("single", None, None, "allreduce"), ("dp", group, None, "allreduce"),
+                                   ("dp3", group, [(11, 16), (3, 11), (0, 3)], "allreduce"), ("sharded", group, None, "sharded"),
+                                   ("sharded3", group, [(11, 16), (3, 11), (0, 3)], "sharded")):
         net = _make(seed=0)
         S = 64
-        engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=pg, bucket_levels=buckets)
+        engine = NAFEngine(net, S, perturb=True, lr=1e-2, process_group=pg, bucket_levels=buckets, dp_mode=mode)
         engine.broadcast_parameters()
         engine.comm_timing(True)
         rays, t_rand, target, mask = _batch(S=S)
@@ -169,7 +183,7 @@ def test_bucketed_rccl_path_with_one_rank_equals_plain_step():
     assert p.exitcode == 0
     emb, mlp, loss, rep = res["single"]
     assert rep is None
-    for tag in ("dp", "dp3"):
+    for tag in ("dp", "dp3", "sharded", "sharded3"):              # ProcessGroupNCCL all-reduce / reduce-scatter / all-gather on buffer slices
         e, m, l, r = res[tag]
         # same records, same integer row sums; only the rare LDS-overflow atomics may reorder
         np.testing.assert_allclose(m, mlp, rtol=0, atol=1e-6)
@@ -201,7 +215,8 @@ def test_bench_two_rank_launch_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 2 * 2048 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert out["allreduce_ms_per_step"] is not None and out["allreduce_bytes"] > 57_000_000
-    assert out["allreduce_exposed_ms_per_step"] is not None and out["allreduce_buckets"] == [[8, 16], [4, 8], [0, 4]]
+    assert out["allreduce_exposed_ms_per_step"] is not None and out["allreduce_buckets"] == [[8, 16], [0, 8]]
+    assert out["grad_exchange"].startswith("reduce-scatter") and out["rays_per_s_per_gpu"] > 0
     assert "cpu_baseline" not in out                               # rank 0 at N = 1 only
 
 

@@ -31,14 +31,18 @@ def _render(net, rays, S, flags, t_rand=None, perturb=True, samples=False, mlp_p
     ws = torch.empty(int(_abi.lib().naf_render_workspace_bytes(ctypes.byref(cfg), n * S)), dtype=torch.uint8, device="cuda")
     acc = torch.empty(n, device="cuda")
     enc = net.encoder
-    args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(enc.embeddings.detach().contiguous()), _abi.ptr(enc.offsets.cuda()),
-            _abi.ptr(net.packed_mlp().detach().contiguous()), _abi.ptr(acc))
+    # the tensors behind these pointers must outlive the launches: keep them in locals (a temporary would be freed, and its block
+    # handed to the next allocation, before the kernel has read it)
+    emb, offs, mlp = enc.embeddings.detach().contiguous(), enc.offsets.cuda(), net.packed_mlp().detach().contiguous()
+    args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(emb), _abi.ptr(offs), _abi.ptr(mlp), _abi.ptr(acc))
     if not samples:
         _abi.check(_abi.lib().naf_render_forward(*args, n, ctypes.byref(cfg), _abi.ptr(ws), _abi.stream_ptr()), "render_forward")
+        torch.cuda.synchronize()
         return acc
     sigma, depth = torch.empty(n, S, device="cuda"), torch.empty(n, S, device="cuda")
     _abi.check(_abi.lib().naf_render_forward_samples(*args, _abi.ptr(sigma), _abi.ptr(depth), n, ctypes.byref(cfg), _abi.ptr(ws),
                                                      _abi.stream_ptr()), "render_forward_samples")
+    torch.cuda.synchronize()
     return acc, sigma, depth
 
 
