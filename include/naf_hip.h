@@ -195,10 +195,15 @@ typedef struct naf_render_cfg {
                                          need no workspace (naf_forward_workspace_bytes).  Bit-identical to the two-kernel path. */
 #define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
                                          (rounds 1-2) instead of one 16-byte window (same results; A/B timing only)      */
-#define NAF_CFG_BACKWARD_SPLIT_2X 128u /* diagnostics: the MLP backward splits rays into tile ranges up to two waves per SIMD          */
-#define NAF_CFG_LEVELS_XCD_PINNED 256u /* the encoder gives XCD k the levels k, k + 8, ... (see encode_kernel)                        */
+#define NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD 128u /* diagnostics: the MLP backward splits rays into tile ranges only up to one wave per SIMD (rounds 1-2) instead of three */
+#define NAF_CFG_LEVELS_XCD_PINNED 256u /* the encoder gives XCD k the levels k, k + 8, ... (see encode_kernel) whatever the batch size;
+                                          without the flag it does so below 120 000 points per call, where that order is faster  */
 #define NAF_CFG_ENCODE_WINDOW4 64u     /* diagnostics: four points per thread in the window encoder instead of two                 */
 #define NAF_CFG_FUSED_STORE_FEATURES 16u /* diagnostics: the fused kernel also stores the features it computed              */
+#define NAF_CFG_TEST_TINY_BLOCKS 4096u   /* tests: the record blocks of pass 1 hold a quarter of a tile's records, so that most
+                                            records take the overflow route (counted global atomics) and the reducer's Adam tail has
+                                            spilled contributions to fold in                                                        */
+
 
 /* Diagnostic (synchronous, host result): number of gradient contributions of the LAST binned backward on this
  * workspace that did not fit their bucket stream and were applied with plain atomics instead (still correct). */
@@ -293,8 +298,9 @@ int naf_field_forward_grid(const double *start, const double *stop, const uint32
  * update to the table rows it has just finished instead of writing their gradient out for naf_adam_step to read back and
  * clear -- the 57 MB (T=2^19) gradient table is then neither written, re-read nor zeroed.  Same results, bit for bit, as
  * naf_render_train followed by naf_adam_step(param, exp_avg, exp_avg_sq, grad_embeddings, param_lp, lp_dtype, n, ...,
- * zero_grad = 1): `grad_embeddings` must be all zero on entry and is all zero on return; the MLP gradient and the loss are
- * written as usual (the caller steps the 4 225 MLP parameters with naf_adam_step, or hands their state over in `adam`).  Batches that take the atomic scatter
+ * zero_grad = 1): `grad_embeddings` must be all zero on entry and is all zero on return; the MLP gradient is written as usual
+ * (the caller steps the 4 225 MLP parameters with naf_adam_step, or hands their state over in `adam`); loss_out[0] is
+ * OVERWRITTEN with this step's loss (a whole optimiser step has nothing to accumulate into; it spares the caller a clear).  Batches that take the atomic scatter
  * (< 2^13 points) or split reducer launches run the two passes one after the other inside the call.
  * `embeddings` is what the kernels gather from (the 16-bit shadow `param_lp` in 16-bit mode, `param` itself in fp32 mode). */
 typedef struct naf_table_adam {

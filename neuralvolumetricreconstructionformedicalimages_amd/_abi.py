@@ -24,8 +24,9 @@ CFG_FORWARD_FUSED = 8
 CFG_FUSED_STORE_FEATURES = 16
 CFG_ENCODE_TWO_GATHERS = 32
 CFG_ENCODE_WINDOW4 = 64
-CFG_BACKWARD_SPLIT_2X = 128
+CFG_BACKWARD_ONE_WAVE_PER_SIMD = 128
 CFG_LEVELS_XCD_PINNED = 256
+CFG_TEST_TINY_BLOCKS = 4096
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}

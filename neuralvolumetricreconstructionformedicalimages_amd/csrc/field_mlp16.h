@@ -28,20 +28,6 @@ typedef short i16x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t feat16(uint32_t g, uint32_t j) { return j < 4u ? 4u * g + j : 12u + 4u * g + j; }
 
-// value W(f)[row m][k] of weight fragment f (same enumeration as field_mlp.h: kFW0 .. kFW2bT)
-__device__ __forceinline__ float wfrag16_value(const float *__restrict__ mlp, uint32_t f, uint32_t m, uint32_t k) {
-    switch (f) {
-        case kFW0:   return mlp[kW0 + m * 32u + k];
-        case kFW1:   return mlp[kW1 + m * 32u + k];
-        case kFW2a:  return mlp[kW2 + m * 64u + k];
-        case kFW2b:  return mlp[kW2 + m * 64u + 32u + k];
-        case kFW0T:  return mlp[kW0 + k * 32u + m];
-        case kFW1T:  return mlp[kW1 + k * 32u + m];
-        case kFW2aT: return mlp[kW2 + k * 64u + m];
-        default:     return mlp[kW2 + k * 64u + 32u + m];
-    }
-}
-
 // LDS block shared by the waves of a workgroup: [kNumWFrag][2 output halves][64 lanes] x 16 B, then b0 b1 b2 w3 (32 floats
 // each) and b3.
 struct Mlp16Shared {
@@ -50,22 +36,43 @@ struct Mlp16Shared {
     static constexpr uint32_t kBiasOff = kNumWFrag * kFragBytes;
     static constexpr uint32_t kBytes = kBiasOff + (4u * 32u + 4u) * 4u;
 
-    static __device__ __forceinline__ void build(unsigned char *lds, const float *__restrict__ mlp, uint32_t n_frags) {
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // Every 256-thread workgroup builds its own copy at kernel start, and at the reference's batch size (1 024 rays: a few tiles per
+    // wave) that prologue is a visible share of the MLP kernels.  The element index of W(f)[m][k] is base + m * sm + k * sk for
+    // every fragment -- no branch on f -- so a wave issues the loads of ALL its (fragment, half) blocks back to back and pays one
+    // L2 round trip instead of one per block (kFrags = 4: two blocks per wave, 8: four).
+    template <uint32_t kFrags>
+    static __device__ __forceinline__ void build(unsigned char *lds, const float *__restrict__ mlp) {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;          // blockDim.x == 256 (four waves)
         const uint32_t r = lane & 15u, g = lane >> 4;
-        for (uint32_t fo = wave; fo < 2u * n_frags; fo += n_waves) {
-            const uint32_t f = fo >> 1, o = fo & 1u;
-            bf16x8 v;
+        constexpr uint32_t kIter = 2u * kFrags / 4u;
+        float v[kIter][8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) v[j] = (__bf16)wfrag16_value(mlp, f, 16u * o + r, feat16(g, j));
-            reinterpret_cast<bf16x8 *>(lds + f * kFragBytes + o * kHalfBytes)[lane] = v;
+        for (uint32_t it = 0; it < kIter; ++it) {
+            const uint32_t fo = wave + 4u * it, f = fo >> 1, o = fo & 1u;
+            const uint32_t layer = f & 3u;                                         // 0: W0, 1: W1, 2: W2[:, :32], 3: W2[:, 32:]
+            const uint32_t base = layer == 0u ? kW0 : layer == 1u ? kW1 : layer == 2u ? kW2 : kW2 + 32u;
+            const uint32_t pitch = layer >= 2u ? 64u : 32u;
+            const bool transposed = f >= kFW0T;
+            const uint32_t sm = transposed ? 1u : pitch, sk = transposed ? pitch : 1u;
+            const uint32_t m = 16u * o + r;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) v[it][j] = mlp[base + m * sm + feat16(g, j) * sk];
         }
         float *bias = reinterpret_cast<float *>(lds + kBiasOff);
-        for (uint32_t i = threadIdx.x; i < 129u; i += blockDim.x) {
-            const uint32_t k = i >> 5, j = i & 31u;
-            const uint32_t src = k == 0 ? kB0 + j : k == 1 ? kB1 + j : k == 2 ? kB2 + j : k == 3 ? kW3 + j : kB3;
-            bias[i] = mlp[src];
+        float bv = 0.0f;
+        if (threadIdx.x < 129u) {
+            const uint32_t k = threadIdx.x >> 5, j = threadIdx.x & 31u;
+            bv = mlp[k == 0 ? kB0 + j : k == 1 ? kB1 + j : k == 2 ? kB2 + j : k == 3 ? kW3 + j : kB3];
         }
+#pragma unroll
+        for (uint32_t it = 0; it < kIter; ++it) {
+            const uint32_t fo = wave + 4u * it, f = fo >> 1, o = fo & 1u;
+            bf16x8 pk;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) pk[j] = (__bf16)v[it][j];
+            reinterpret_cast<bf16x8 *>(lds + f * kFragBytes + o * kHalfBytes)[lane] = pk;
+        }
+        if (threadIdx.x < 129u) bias[threadIdx.x] = bv;
         __syncthreads();
     }
     static __device__ __forceinline__ bf16x8 frag(const unsigned char *lds, uint32_t f, uint32_t o, uint32_t lane) {

@@ -219,7 +219,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
                      float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items, uint32_t B, int act,
                      OutMap omap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Mlp16Shared::build(smem, mlp, 4);
+    Mlp16Shared::build<4>(smem, mlp);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
     Act16 a;
@@ -285,7 +285,7 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
     constexpr uint32_t kShAligned = (Mlp16Shared::kBytes + 15u) & ~15u;
     LevelRec *recs = reinterpret_cast<LevelRec *>(smem + kShAligned);
     build_level_recs(recs, offsets, kFusedLevels, H);
-    Mlp16Shared::build(smem, mlp, 4);                          // ends with a workgroup barrier: the level records are visible too
+    Mlp16Shared::build<4>(smem, mlp);                          // ends with a workgroup barrier: the level records are visible too
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t table_rows = (uint32_t)offsets[kFusedLevels];
@@ -341,6 +341,10 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
 // slab layout == parameter block layout (kW0 .. kB3), one slab of kSlabStride floats per workgroup.
 constexpr uint32_t kSlabStride = 4352;
 constexpr uint32_t kSlabLoss = kMlpParams;         // slab entry behind the parameter block: the workgroup's share of the loss
+// ... and behind that the bit pattern of the workgroup's max |feature gradient| (the fixed-point scale of the binned scatter).  It
+// used to be one atomicMax per WAVE on a single word: same-address atomics retire one at a time (~12 ns each, MI355X_MICROARCH.md
+// "fanin"), 1 024 .. 3 072 of them were 12 .. 37 us of a 53 us kernel at 1 024 rays.  The slab reduction takes the maximum instead.
+constexpr uint32_t kSlabGmax = kMlpParams + 1u;
 
 // Training steps hand the backward kernels what the loss needs instead of a precomputed d loss / d acc: the masked squared error
 // of train.py:127 / loss.py:37 in weighted form, loss = sum_r w_r (acc_r - y_r)^2, d loss / d acc_r = 2 w_r (acc_r - y_r), is two
@@ -361,7 +365,7 @@ template <typename P, uint32_t C>
 __global__ void __launch_bounds__(256)
 mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                     const float *__restrict__ grad_acc, LossInputs loss, typename P::feat_t::store_t *__restrict__ dfeat,
-                    float *__restrict__ slabs, uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act) {
+                    float *__restrict__ slabs, uint32_t n_rays, uint32_t B, int act) {
     using Sh = MlpShared<P>;
     using TR = typename P::tr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -485,11 +489,8 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
         }
     }
 
-    if (gmax_bits != nullptr) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
-        if (lane == 0 && dmax != 0u) atomicMax(gmax_bits, dmax);                        // non-negative floats order like uints
-    }
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));     // non-negative floats order like uints
 
     // ---- fold the 4 waves of the workgroup into one slab (fixed order -> deterministic), then one store ------
     __syncthreads();                                        // everyone is done with the transpose images
@@ -520,12 +521,16 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
                 red[kB1 + n] = (first ? 0.0f : red[kB1 + n]) + db1;
                 red[kB2 + n] = (first ? 0.0f : red[kB2 + n]) + db2;
             }
-            if (lane == 0) { red[kB3] = (first ? 0.0f : red[kB3]) + db3; red[kSlabLoss] = (first ? 0.0f : red[kSlabLoss]) + loss_part; }
+            if (lane == 0) {
+                red[kB3] = (first ? 0.0f : red[kB3]) + db3;
+                red[kSlabLoss] = (first ? 0.0f : red[kSlabLoss]) + loss_part;
+                red[kSlabGmax] = __uint_as_float(first ? dmax : max(dmax, __float_as_uint(red[kSlabGmax])));
+            }
         }
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
-    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) slab[i] = red[i];
+    for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) slab[i] = red[i];
 }
 
 // ---- 3b: MLP backward on 16-point tiles (bf16 mode, C = 2; field_mlp16.h) ----------------------------------------
@@ -533,9 +538,9 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
 __global__ void __launch_bounds__(256, 3)                     // 168 VGPRs (11 spilled dwords): three waves per SIMD
 mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                       const float *__restrict__ grad_acc, LossInputs loss, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
-                      uint32_t *__restrict__ gmax_bits, uint32_t n_rays, uint32_t B, int act, uint32_t log2_parts) {
+                      uint32_t n_rays, uint32_t B, int act, uint32_t parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Mlp16Shared::build(smem, mlp, 8);
+    Mlp16Shared::build<8>(smem, mlp);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
     // wave-uniform values are made scalar explicitly: the ray record, its depths range and d acc then live in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -563,16 +568,17 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     uint32_t dmax = 0u;                                      // see mlp_backward_kernel
     f32x4v dw3lo = zero4, dw3hi = zero4;
 
-    // A work item is one ray, or one of 2^log2_parts consecutive tile ranges of a ray when there are fewer rays than waves
-    // (1 024-ray steps: two waves per ray; the backward of a sample needs nothing of its ray but d acc, so the ranges are
-    // independent): twice the waves per SIMD to hide the latency of the dependent MFMA chain behind.
+    // A work item is one ray, or one of `parts` consecutive tile ranges of a ray when there are fewer rays than resident waves
+    // (1 024-ray steps: three waves per ray, four tiles each; the backward of a sample needs nothing of its ray but d acc, so
+    // the ranges are independent): more waves per SIMD to hide the latency of the dependent MFMA chain behind.
     const uint32_t S = src.S, tiles = (S + 15u) / 16u;
-    const uint32_t n_items = n_rays << log2_parts, part_mask = (1u << log2_parts) - 1u;
-    auto first_tile = [&](uint32_t item) { return ((item & part_mask) * tiles) >> log2_parts; };
+    const uint32_t n_items = n_rays * parts;
+    auto ray_of = [&](uint32_t item) { return item / parts; };
+    auto first_tile = [&](uint32_t part) { return part * tiles / parts; };
     Feat16Raw ahead;
-    if (wave < n_items) load_feat16(feat, B, (wave >> log2_parts) * S + min(16u * first_tile(wave) + c, S - 1u), g, ahead);
+    if (wave < n_items) load_feat16(feat, B, ray_of(wave) * S + min(16u * first_tile(wave - ray_of(wave) * parts) + c, S - 1u), g, ahead);
     for (uint32_t item = wave; item < n_items; item += n_waves) {
-        const uint32_t r = item >> log2_parts, k_begin = first_tile(item), k_end = (((item & part_mask) + 1u) * tiles) >> log2_parts;
+        const uint32_t r = ray_of(item), part = item - r * parts, k_begin = first_tile(part), k_end = first_tile(part + 1u);
         const float *ray = src.rays + (size_t)r * 8;
         const float near = ray[6], far = ray[7];
         const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
@@ -580,7 +586,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         if (loss.target != nullptr) {                        // training step: the loss lives here (wave-uniform arithmetic)
             const float err = loss.acc[r] - loss.target[r], w = loss.weight[r];
             dacc = 2.0f * w * err;
-            if ((item & part_mask) == 0u) loss_part += w * err * err;      // once per ray, not once per tile range
+            if (part == 0u) loss_part += w * err * err;                    // once per ray, not once per tile range
         } else dacc = grad_acc[r];
         if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
 
@@ -592,8 +598,8 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             {   // the next tile of this item, or the first tile of the wave's next item (a harmless reload at the very end)
                 const bool more = k + 1u < k_end;
                 const uint32_t next = item + n_waves < n_items ? item + n_waves : item;
-                const uint32_t rn = more ? r : next >> log2_parts;
-                const uint32_t sn = more ? s + 16u : 16u * first_tile(next) + c;
+                const uint32_t rn = more ? r : ray_of(next);
+                const uint32_t sn = more ? s + 16u : 16u * first_tile(next - ray_of(next) * parts) + c;
                 load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
             }
             const bf16x8 x0f = feat16_operand(now);
@@ -692,11 +698,8 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         }
     }
 
-    if (gmax_bits != nullptr) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
-        if (lane == 0 && dmax != 0u) atomicMax(gmax_bits, dmax);                        // non-negative floats order like uints
-    }
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));     // non-negative floats order like uints
 
     // ---- fold the 4 waves of the workgroup into one slab (wave order -> deterministic), then one store ---------------
 #pragma unroll
@@ -714,7 +717,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     }
     __syncthreads();                                                                // images / depth buffers are dead
     float *red = reinterpret_cast<float *>(smem + kShAligned);
-    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) red[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) red[i] = 0.0f;
     __syncthreads();
     for (uint32_t w = 0; w < 4u; ++w) {
         if (wib == w) {
@@ -746,12 +749,16 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
                     red[kW3 + 16u + 4u * g + j] += dw3hi[j];
                 }
             }
-            if (lane == 0u) { red[kB3] += db3; red[kSlabLoss] += loss_part; }
+            if (lane == 0u) {
+                red[kB3] += db3;
+                red[kSlabLoss] += loss_part;
+                red[kSlabGmax] = __uint_as_float(max(dmax, __float_as_uint(red[kSlabGmax])));      // +0.0f = bits 0 at the start
+            }
         }
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
-    for (uint32_t i = threadIdx.x; i <= kSlabLoss; i += blockDim.x) slab[i] = red[i];
+    for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) slab[i] = red[i];
 }
 
 // ---- 5: slabs -> grad_mlp (+=) and loss (+=), summed in a fixed order (deterministic) ---------------------------------
@@ -759,30 +766,47 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
 // combined through LDS in group order.  Entry kSlabLoss is the loss.  With `adam.param` set the finished sum of a parameter goes
 // straight into its Adam update (same expression as adam_kernel: adam_math.h) and the gradient buffer stays as it was.
 constexpr uint32_t kReduceParams = 32, kReduceGroups = 32;
+enum LossMode : int { kLossNone = 0, kLossAdd = 1, kLossAssign = 2 };       // loss_out[0] untouched / += / = the step's loss
 __global__ void __launch_bounds__(1024)
 mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp, float *__restrict__ loss_out,
-                       bool with_loss, MlpAdam adam) {
+                       int loss_mode, MlpAdam adam, uint32_t *__restrict__ gmax_out, uint32_t *__restrict__ clear_words, uint32_t n_clear) {
     __shared__ float part[kReduceGroups][kReduceParams];
+    // the overflow counters of the binned scatter that follows on the stream (one tiny launch less per step than a memset)
+    if (blockIdx.x == 0u && threadIdx.x < n_clear) clear_words[threadIdx.x] = 0u;
     const uint32_t j = threadIdx.x % kReduceParams, g = threadIdx.x / kReduceParams;
     const uint32_t i = blockIdx.x * kReduceParams + j;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (i <= kSlabLoss) {
-        uint32_t k = g;
-        for (; k + 3u * kReduceGroups < n_slabs; k += 4u * kReduceGroups) {
-            s0 += slabs[(size_t)(k + 0u * kReduceGroups) * kSlabStride + i];
-            s1 += slabs[(size_t)(k + 1u * kReduceGroups) * kSlabStride + i];
-            s2 += slabs[(size_t)(k + 2u * kReduceGroups) * kSlabStride + i];
-            s3 += slabs[(size_t)(k + 3u * kReduceGroups) * kSlabStride + i];
+    if (i == kSlabGmax) {                                    // max |feature gradient| of the step: bit patterns, integer maximum
+        uint32_t m = 0u;
+        for (uint32_t k = g; k < n_slabs; k += kReduceGroups) m = max(m, __float_as_uint(slabs[(size_t)k * kSlabStride + i]));
+        part[g][j] = __uint_as_float(m);
+    } else {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        if (i <= kSlabLoss) {
+            uint32_t k = g;
+#pragma unroll 2
+            for (; k + 3u * kReduceGroups < n_slabs; k += 4u * kReduceGroups) {
+                s0 += slabs[(size_t)(k + 0u * kReduceGroups) * kSlabStride + i];
+                s1 += slabs[(size_t)(k + 1u * kReduceGroups) * kSlabStride + i];
+                s2 += slabs[(size_t)(k + 2u * kReduceGroups) * kSlabStride + i];
+                s3 += slabs[(size_t)(k + 3u * kReduceGroups) * kSlabStride + i];
+            }
+            for (; k < n_slabs; k += kReduceGroups) s0 += slabs[(size_t)k * kSlabStride + i];
         }
-        for (; k < n_slabs; k += kReduceGroups) s0 += slabs[(size_t)k * kSlabStride + i];
+        part[g][j] = (s0 + s1) + (s2 + s3);
     }
-    part[g][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && i <= kSlabLoss) {
+    if (g == 0 && i == kSlabGmax) {
+        uint32_t m = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < kReduceGroups; ++q) m = max(m, __float_as_uint(part[q][j]));
+        if (gmax_out != nullptr) *gmax_out = m;
+    } else if (g == 0 && i <= kSlabLoss) {
         float total = 0.0f;
 #pragma unroll
         for (uint32_t q = 0; q < kReduceGroups; ++q) total += part[q][j];
-        if (i == kSlabLoss) { if (with_loss && loss_out != nullptr) loss_out[0] += total; }
+        if (i == kSlabLoss) {
+            if (loss_mode != kLossNone && loss_out != nullptr) loss_out[0] = loss_mode == kLossAssign ? total : loss_out[0] + total;
+        }
         else if (adam.param != nullptr) {
             const float gsum = grad_mlp[i] + total;          // whatever the caller had accumulated there (+=), as adam_kernel would see it
             float p = adam.param[i], m = adam.m[i], v = adam.v[i];
@@ -814,7 +838,7 @@ template <typename P>
 static uint32_t backward_lds_bytes() {
     const uint32_t sh = (MlpShared<P>::kBytes + 15u) & ~15u;
     const uint32_t imgs = ((4u * 3u * 32u * P::kTrPitch * (uint32_t)sizeof(typename P::tr_t)) + 15u) & ~15u;
-    return sh + std::max<uint32_t>(imgs + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
+    return sh + std::max<uint32_t>(imgs + 4u * kMaxSamplesLds * 4u, (kMlpParams + 2u) * 4u);
 }
 
 struct Workspace {
@@ -863,6 +887,7 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     // would fit the LDS next to a second workgroup, but the larger allocation measured 2-3 % slower.  A multiple of 32
     // records: blocks start on 128-byte lines.
     plan->slots = std::min<uint32_t>(65504u, ((tile * 11u / 2u) + 31u) & ~31u);
+    if ((cfg->flags & NAF_CFG_TEST_TINY_BLOCKS) != 0u) plan->slots = std::max(32u, tile & ~31u);      // a quarter of a tile's records fit
     // pass 2 reads a bucket's run of a tile with W lanes: W = the power of two >= 1.25 x the mean run length, at most a wave
     const uint32_t mean_run = std::max<uint32_t>(1u, (tile * 4u) >> log2_nb);
     plan->log2_w = 3u;
@@ -911,7 +936,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_SPLIT_2X | NAF_CFG_LEVELS_XCD_PINNED)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_LEVELS_XCD_PINNED | NAF_CFG_TEST_TINY_BLOCKS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1038,10 +1063,14 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     }
     const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
     const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
-    const bool pinned = !interleaved && (cfg->flags & NAF_CFG_LEVELS_XCD_PINNED) != 0u && cfg->L >= 8u;
+    // small batches pull every level through all eight L2s for a handful of points each: below ~600 rays x 192 samples the pinned
+    // order wins (256 rays: 0.036 -> 0.024 ms, 512: 0.047 -> 0.040), from 1 024 rays on level-major does (0.067 vs 0.070)
+    constexpr uint32_t kPinnedMaxPoints = 120000u;
+    const bool pinned = !interleaved && cfg->L >= 8u && ((cfg->flags & NAF_CFG_LEVELS_XCD_PINNED) != 0u || B <= kPinnedMaxPoints);
     const uint32_t order = interleaved ? 1u : pinned ? 2u : 0u;
-    // pinned: 8 XCDs x up to 256 workgroups each (32 CUs x 4 waves per SIMD = 8 workgroups of 4 waves per CU)
-    const dim3 grid = interleaved ? dim3(cfg->L, gx) : pinned ? dim3(8u * std::min(gx, 256u)) : dim3(gx, cfg->L);
+    // pinned: 8 XCDs x up to 160 workgroups each = what is resident at once (32 CUs x 5 waves per SIMD at 94 VGPRs; more would queue
+    // behind the first round on some XCDs and unbalance them)
+    const dim3 grid = interleaved ? dim3(cfg->L, gx) : pinned ? dim3(8u * std::min(gx, 160u)) : dim3(gx, cfg->L);
     { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
                        (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, order, cfg->L, cfg->L); }
     return check_launch("encode_kernel");
@@ -1079,11 +1108,18 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     return check_launch("mlp_forward_kernel");
 }
 
-static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad_mlp, float *loss_out, bool with_loss, const MlpAdam *madam, hipStream_t s) {
+// What a training step hands down so that its small clears ride on kernels it launches anyway: `clear_words` -- counters the slab
+// reduction zeroes (the overflow counters of the binned scatter); `loss_assign` -- loss_out[0] = loss instead of +=.
+struct StepExtras { uint32_t *clear_words; uint32_t n_clear; bool loss_assign; };
+constexpr StepExtras kNoExtras{nullptr, 0u, false};
+
+static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad_mlp, float *loss_out, bool with_loss, const MlpAdam *madam,
+                               uint32_t *gmax_bits, const StepExtras &ex, hipStream_t s) {
     const MlpAdam none{nullptr, nullptr, nullptr, AdamArgs{}};
     ProfScope prof_("mlp_grad_reduce_kernel", s);
-    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kSlabLoss + 1u + kReduceParams - 1u) / kReduceParams), dim3(kReduceParams * kReduceGroups), 0, s,
-                       slabs, n_slabs, grad_mlp, loss_out, with_loss, madam != nullptr ? *madam : none);
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kSlabGmax + 1u + kReduceParams - 1u) / kReduceParams), dim3(kReduceParams * kReduceGroups), 0, s,
+                       slabs, n_slabs, grad_mlp, loss_out, !with_loss ? kLossNone : ex.loss_assign ? kLossAssign : kLossAdd,
+                       madam != nullptr ? *madam : none, gmax_bits, ex.clear_words, ex.clear_words != nullptr ? ex.n_clear : 0u);
     return check_launch("mlp_grad_reduce_kernel");
 }
 
@@ -1092,40 +1128,40 @@ static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad
 template <typename P, uint32_t C>
 static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &src, const float *grad_acc, const LossInputs &loss, void *dfeat,
                             float *slabs, uint32_t *gmax_bits, float *grad_mlp, float *loss_out, const MlpAdam *madam, uint32_t n_rays, uint32_t B,
-                            const naf_render_cfg *cfg, hipStream_t s) {
+                            const naf_render_cfg *cfg, const StepExtras &ex, hipStream_t s) {
     const bool with_loss = loss.target != nullptr;
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
         {
             const uint32_t sh16 = (Mlp16Shared::kBytes + 15u) & ~15u;
-            const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 1u) * 4u);
-            if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
-            // fewer rays than the chip has SIMDs (1 024): up to 8 tile ranges per ray, never more ranges than tiles, so that every
-            // SIMD gets a wave; NAF_CFG_BACKWARD_SPLIT_2X (diagnostic) goes on to two waves per SIMD
+            const uint32_t lds16 = sh16 + std::max<uint32_t>(4u * 3u * 1024u + 4u * kMaxSamplesLds * 4u, (kMlpParams + 2u) * 4u);
+            // fewer rays than the chip holds waves of this kernel (3 per SIMD = 3 072): `parts` tile ranges per ray, never more
+            // ranges than tiles, so that the resident waves all get one item of equal length where the numbers allow it
+            // (1 024 rays x 12 tiles: 3 parts of 4 tiles).  NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD (diagnostic): the old goal of one wave per SIMD.
             const uint32_t tiles = (cfg->n_samples + 15u) / 16u;
-            const uint64_t wave_goal = (cfg->flags & NAF_CFG_BACKWARD_SPLIT_2X) != 0u ? 2048u : 1024u;
-            uint32_t log2_parts = 0;
-            while (log2_parts < 3u && ((uint64_t)n_rays << (log2_parts + 1u)) <= wave_goal && (2u << log2_parts) <= tiles) ++log2_parts;
-            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((((uint64_t)n_rays << log2_parts) + 3) / 4, kBackwardBlocks16));
+            const uint64_t wave_goal = (cfg->flags & NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD) != 0u ? 1024u : 4u * kBackwardBlocks16;
+            const uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(tiles, 12u), wave_goal / std::max<uint32_t>(n_rays, 1u)));
+            const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays * parts + 3) / 4, kBackwardBlocks16));
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
-                               grad_acc, loss, (uint16_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation, log2_parts); }
+                               grad_acc, loss, (uint16_t *)dfeat, slabs, n_rays, B, cfg->last_activation, parts); }
             if (int rc = check_launch("mlp16_backward_kernel")) return rc;
-            return run_mlp_grad_reduce(slabs, grid16, grad_mlp, loss_out, with_loss, madam, s);
+            return run_mlp_grad_reduce(slabs, grid16, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
         }
     }
     auto kern = mlp_backward_kernel<P, C>;
     const uint32_t lds = backward_lds_bytes<P>();
     if (int rc = raise_lds_limit(kern, lds, "mlp_backward_kernel: cannot raise dynamic LDS limit")) return rc;      // fp32 images need > 64 KiB
-    if (gmax_bits != nullptr && hipMemsetAsync(gmax_bits, 0, 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp_backward: memset failed");
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc, loss,
-                       (typename P::feat_t::store_t *)dfeat, slabs, gmax_bits, n_rays, B, cfg->last_activation); }
+                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
-    return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, s);
+    return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
 }
 
-// Workgroups a reducer launch over `nl` levels splits each bucket's tiles between: 1 when buckets x levels already fill the chip
-// twice over, more (with per-row atomics at the end) when a pass holds only a few levels.
-static uint32_t reducer_split(uint32_t NB, uint32_t nl) { return NB * nl >= 512u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl))); }
+// Workgroups a reducer launch over `nl` levels splits each bucket's tiles between: 1 when buckets x levels give every CU a
+// workgroup (one owner per row, sums formed in a fixed order: the table gradient is bit-reproducible -- this covers the four-level
+// buckets of a data-parallel step, 64 x 4 = 256), more (with per-row fp32 atomics at the end, whose order is not fixed) only when a
+// pass holds fewer than four levels' worth of buckets.
+static uint32_t reducer_split(uint32_t NB, uint32_t nl) { return NB * nl >= 256u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl))); }
 // The Adam tail (naf_render_train_adam) needs every reducer launch of the step unsplit, the binned scatter and level-major launches.
 static bool adam_tail_possible(const naf_render_cfg *cfg, const Workspace &w) {
     if (!w.binned || per_level_launches(cfg)) return false;
@@ -1236,8 +1272,8 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr) {
-    if (w.binned && hipMemsetAsync(w.overflow, 0, 33 * 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
+                             const AdamTail *adam = nullptr, bool overflow_cleared = false) {
+    if (w.binned && !overflow_cleared && hipMemsetAsync(w.overflow, 0, 33 * 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
     if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam);
     if (adam != nullptr) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: the Adam tail cannot be combined with gradient buckets");
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
@@ -1315,7 +1351,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
                                 void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
                                 const AdamTail *adam = nullptr, bool from_train = false, const LossInputs &loss = LossInputs{nullptr, nullptr, nullptr},
-                                float *loss_out = nullptr, const MlpAdam *madam = nullptr) {
+                                float *loss_out = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
@@ -1328,24 +1364,28 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     // (a fused forward of the same cfg left no features behind unless it was asked to store them)
     if (!features_valid || (forward_fused(cfg) && (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) == 0u && !from_train))
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, loss, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, loss_out, madam, n_rays, B, cfg, s)) return rc;
+    // a training step's small clears ride on its own kernels: the slab reduction writes the gradient maximum and zeroes the
+    // overflow counters of the scatter (three memset launches of ~5 us each were 4 % of the reference-size step)
+    const StepExtras ex{w.binned ? w.overflow : nullptr, 33u, loss_assign};
+    if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, loss, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, loss_out, madam, n_rays, B, cfg,
+                                        from_train ? ex : kNoExtras, s)) return rc;
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, from_train && w.binned);
 }
 
 template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr) {
+                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true)) return rc;
-    // the masked squared error and its gradient are formed inside the backward kernel (LossInputs); the loss reaches loss_out (+=)
+    // the masked squared error and its gradient are formed inside the backward kernel (LossInputs); the loss reaches loss_out
     // through the slab reduction that also finishes the MLP gradient
     const LossInputs loss{acc, target, ray_weight};
     return render_backward_impl<P, C>(rays, t_rand, nullptr, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true,
-                                      loss, loss_out, madam);
+                                      loss, loss_out, madam, loss_assign);
 }
 
 template <typename P, uint32_t C>
@@ -1486,7 +1526,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream,
-                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr) {
+                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
@@ -1496,6 +1536,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
     if (buckets != nullptr)
         if (int rc = check_buckets(buckets, cfg->L)) return rc;
     if (n_rays == 0) {                                       // an empty shard still has to signal its (zero) gradients as final
+        if (loss_assign && loss_out != nullptr && hipMemsetAsync(loss_out, 0, 4, (hipStream_t)stream) != hipSuccess) return fail(NAF_ERR_LAUNCH, "render_train: memset failed");
         if (buckets != nullptr) {
             if (buckets->mlp_ready && hipEventRecord((hipEvent_t)buckets->mlp_ready, (hipStream_t)stream) != hipSuccess) return fail(NAF_ERR_LAUNCH, "render_train: event");
             for (uint32_t b = 0; b < buckets->n_buckets; ++b)
@@ -1504,7 +1545,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
         return NAF_OK;
     }
     NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam);
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam, loss_assign);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
@@ -1554,10 +1595,10 @@ extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, con
     const uint64_t n_points = (uint64_t)n_rays * cfg->n_samples;
     if (n_rays != 0 && workspace != nullptr && n_points < (1ull << 31) && adam_tail_possible(cfg, carve(workspace, cfg, n_points)))
         return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp);
+                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp, true);
     // small batches (atomic scatter), split reducer launches, per-level diagnostics, empty batches: the two passes one after the other
     if (int rc = render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                    n_rays, cfg, workspace, nullptr, stream, nullptr, mp)) return rc;
+                                    n_rays, cfg, workspace, nullptr, stream, nullptr, mp, true)) return rc;
     return launch_adam(adam->param, adam->exp_avg, adam->exp_avg_sq, grad_embeddings, adam->param_lp, adam->lp_dtype, adam->n, tail.a,
                        true, (hipStream_t)stream);
 }

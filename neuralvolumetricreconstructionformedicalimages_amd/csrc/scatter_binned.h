@@ -207,7 +207,10 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         const uint32_t level = level_base + ly;
         const LevelMeta m = make_level_meta<3>(offsets, level, H);
         float *__restrict__ gg = grad_table + (size_t)m.offset * C;
-        const bool merging = m.scale * spacing < 0.75f;              // wave-uniform, batch-wide
+        // wave-uniform, batch-wide.  The merge key below packs two cell coordinates into 16 bits each: an invariant of the level
+        // (fewer than 2^16 cells per axis), not of ray 0's spacing -- a degenerate first ray (spacing 0) must not switch merging on
+        // for the fine levels, whose keys would alias.
+        const bool merging = m.scale * spacing < 0.75f && m.scale < 65535.0f;
 
         // ---- A: records of the thread's points (registers), histogram -------------------------------------------------
         Rec rec[PTS][4];                                             // the four x-neighbour pairs of a cell

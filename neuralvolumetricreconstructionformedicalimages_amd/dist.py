@@ -36,10 +36,14 @@ def init_from_env(device_type="cuda"):
         backend = os.environ.get("NAF_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
             torch.cuda.set_device(local_device_index())
+        # Rank 0 evaluates alone (a 1024^2 projection + a 512^3 .. 1024^3 volume query) while the other ranks wait at the barrier
+        # behind it: the collective timeout must outlast an evaluation, not a training step (NAF_DIST_TIMEOUT_MIN, default 2 h)
+        import datetime
+        timeout = datetime.timedelta(minutes=float(os.environ.get("NAF_DIST_TIMEOUT_MIN", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index()))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index()), timeout=timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
     return rank, world, local_rank, dist.group.WORLD
 
 

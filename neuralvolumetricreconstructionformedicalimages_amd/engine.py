@@ -455,8 +455,7 @@ class NAFEngine:
         n = rays.shape[0]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
-        self.loss.zero_()
-        cfg = self._cfg(ray_base)                              # the jitter seed of step k, as in backward()
+        cfg = self._cfg(ray_base)                              # the jitter seed of step k, as in backward()  (the call overwrites self.loss)
         self.step_count += 1                                   # ... and the Adam step count k + 1, as in optimizer_step()
         ws = fused.workspace(cfg, n * self.n_samples, self.device)
         b1, b2 = self.betas

@@ -101,7 +101,8 @@ class RayGenerator:
             float(self.near), float(self.far), int(g.mode == "parallel"), _abi.stream_ptr()), "generate_rays")
         return out
 
-    def draw(self, valid_lists, rays_per_list, seed, projections=None, first=0, count=None, rays_out=None, want_pixels=True):
+    def draw(self, valid_lists, rays_per_list, seed, projections=None, first=0, count=None, rays_out=None, want_pixels=True,
+             target_out=None):
         """`rays_per_list` distinct entries of each list in `valid_lists` (int64 device tensors of flat pixel indices),
         drawn on the device by `naf_draw_scan_rays` -> (pixels [n] or None, target [n] or None, rays [n, 8]).
         `first` / `count` select a slice of the len(valid_lists) * rays_per_list draws (data-parallel shards)."""
@@ -119,7 +120,9 @@ class RayGenerator:
             st.valid[j], st.n_valid[j] = v.data_ptr(), v.numel()
         rays = rays_out if rays_out is not None else torch.empty(count, 8, device=self.device, dtype=torch.float32)
         pixels = torch.empty(count, device=self.device, dtype=torch.int64) if want_pixels else None
-        target = torch.empty(count, device=self.device, dtype=torch.float32) if projections is not None else None
+        target = None
+        if projections is not None:
+            target = target_out if target_out is not None else torch.empty(count, device=self.device, dtype=torch.float32)
         import ctypes
         _abi.check(_abi.lib().naf_draw_scan_rays(
             ctypes.byref(st), _abi.ptr(self.poses), _abi.ptr(projections), _abi.ptr(pixels), _abi.ptr(target), _abi.ptr(rays),

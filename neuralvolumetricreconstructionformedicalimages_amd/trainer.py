@@ -102,6 +102,7 @@ class Trainer:
         self.loss_mode = backend.get("loss", "chunk_sum")
         self.i_log = int(cfg["log"].get("i_log", 100))      # steps between train/loss scalars (reading the loss synchronises)
         self._plain_weights = {}
+        self._draw_ahead = None
         self._even_shards = cfg["train"]["n_rays"] % max(self.world, 1) == 0     # every rank then holds n_rays / world rays
 
         self.expdir = osp.join(cfg["exp"]["expdir"], cfg["exp"]["expname"])
@@ -164,6 +165,8 @@ class Trainer:
             if self.engine is not None:
                 self.engine.sync_from_module()
             self.global_step = self.epoch_start * len(self.train_dloader)
+            # the pixel draws are keyed by (seed, item count): a resumed run continues the sequence instead of replaying epoch 0's
+            self.train_dset.set_draw_position(self.global_step)
 
         self.writer = SummaryWriter(self.expdir) if (SummaryWriter is not None and self.rank == 0) else _NullWriter()
         self.writer.add_text("parameters", self.args2string(cfg), global_step=0)
@@ -196,6 +199,11 @@ class Trainer:
                 self.net.train()
                 msg = "".join(f", {k}: {float(v):.3g}" for k, v in loss_test.items())
                 print(f"[EVAL] epoch: {idx_epoch}/{self.epochs}{msg}")
+            if self.group is not None and self.i_eval > 0 and (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs):
+                # rank 0 evaluated alone: the other ranks wait HERE (a barrier under the long group timeout of dist.init_from_env),
+                # not inside the first gradient exchange of the next step
+                import torch.distributed as tdist
+                tdist.barrier(group=self.group)
 
             for data in self._batches():
                 self.global_step += 1
@@ -219,9 +227,20 @@ class Trainer:
         whose items already are whole ray batches (trainer.py:32-37); with the fused engine the items are consumed directly --
         the collate step would only copy every tensor once more to add a batch dimension of one."""
         if self.engine is not None and self.conf["train"]["n_batch"] == 1:
-            dset = self.train_dset
-            return (dset[i] for i in range(len(dset)))
+            return self._items_drawn_ahead()
         return iter(self.train_dloader)
+
+    def _items_drawn_ahead(self):
+        """The items of one epoch, each drawn on a side stream while the previous step computes (dataset.DrawAhead): the draw is
+        one small launch that depends on nothing the step produces.  Items are numbered over the whole run (item k is
+        dataset[k % len]), so the keyed pixel draws follow the same sequence with and without the look-ahead."""
+        dset = self.train_dset
+        if self._draw_ahead is None:
+            from .dataset import DrawAhead
+            self._draw_ahead = DrawAhead(lambda k, slot: dset[k % len(dset)], self.device)
+        first = self.global_step                              # items consumed so far (resume included)
+        for i in range(len(dset)):
+            yield self._draw_ahead.get(first + i)
 
     def save_checkpoint(self, idx_epoch):
         if self.rank != 0:                                 # replicas are identical; rank 0 writes

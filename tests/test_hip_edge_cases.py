@@ -181,6 +181,34 @@ def test_table_adam_in_the_reducer_equals_the_separate_passes(table_dtype, log2T
     assert float((out[True][0] - naf_pair(seed=33, log2T=log2T, oracle=False)[0].encoder.embeddings.data).abs().max()) > 0     # it trained
 
 
+@pytest.mark.parametrize("table_dtype", [torch.float32, torch.bfloat16])
+def test_adam_tail_folds_in_records_that_overflowed_their_blocks(table_dtype):
+    """The `spilled` branch of the reducer's Adam tail: with NAF_CFG_TEST_TINY_BLOCKS a pass-1 block holds a quarter of its tile's
+    records, the rest reach the gradient table through counted global atomics, and the tail must add them to its own sums and
+    clear them.  Against the separate route (reducer adds its sums to the table, naf_adam_step consumes and clears it) on the
+    same tiny blocks -- equal up to the order of the fp32 atomics -- and against the ordinary step without overflow."""
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    n, S = 300, 48
+    rays = crossing_rays(n, seed=31).cuda()
+    target = torch.rand(n, device="cuda") * 0.2
+    weight = torch.full((n,), 1.0 / n, device="cuda")
+    out = {}
+    for tag, fuse, flags in (("tail", True, _abi.CFG_TEST_TINY_BLOCKS), ("separate", False, _abi.CFG_TEST_TINY_BLOCKS), ("plain", True, 0)):
+        net, _ = naf_pair(seed=33, log2T=14, oracle=False)
+        eng = NAFEngine(net, S, perturb=True, lr=3e-3, table_dtype=table_dtype, fuse_table_adam=fuse, cfg_flags=flags, scatter_mode=2)
+        for step in range(3):
+            eng.train_step(rays, target, weight, ray_base=step * n)
+        torch.cuda.synchronize()
+        spilled = eng.scatter_overflow(n)
+        assert (spilled > 0) == (flags != 0), (tag, spilled)             # the tiny blocks really overflowed, the ordinary ones did not
+        assert float(eng.emb_g.abs().max()) == 0.0                       # whatever the atomics left in the table was consumed
+        out[tag] = (eng.emb.clone(), eng.emb_m.clone(), eng.emb_v.clone())
+    for other in ("separate", "plain"):
+        for a, b in zip(out["tail"], out[other]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3), other
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_padding_of_the_last_tile_emits_no_records(prec):
     """300 rays x 48 samples = 14 400 points end 64 points into a pass-1 tile, and every ray's last sample is clamped onto a face

@@ -29,11 +29,11 @@ for f in files:
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
 for k, cs in sorted(agg.items()):
-    if not any(s in k for s in ("encode", "scatter", "mlp", "adam", "hash_")):
+    if not any(s in k for s in ("encode", "scatter", "mlp", "adam", "hash_", "fused_forward", "draw_scan")):
         continue
-    row = {c: sum(v) / len(v) * 1024 for c, v in cs.items()}
+    row = {c: sum(v) / len(v) * (1024 if c.endswith("_SIZE") else 1) for c, v in cs.items()}     # *_SIZE are in KiB, the rest are counts
     row["dispatches"] = max(len(v) for v in cs.values())
     summary[k] = row
-    print(f"{k:28s} n={row['dispatches']:3d} " + " ".join(f"{c}={row[c]/1e6:10.1f} MB/dispatch" for c in cs))
+    print(f"{k:28s} n={row['dispatches']:3d} " + " ".join(f"{c}={row[c]/1e6:10.1f} {'MB' if c.endswith('_SIZE') else 'M'}/dispatch" for c in cs))
 if out_json:
     json.dump(summary, open(out_json, "w"), indent=1)

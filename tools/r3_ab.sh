@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-3 A/B runs of the training step (diagnostic flags); output: gpurun_out/r3c/ab.jsonl (one line per variant)
-OUT=gpurun_out/r3c
+# round-3 A/B runs of the training step (diagnostic flags); output: $OUT/ab.jsonl (one line per variant)
+OUT=${OUT:-gpurun_out/r3c}
 mkdir -p $OUT
 B="--cpu-seconds 0 --sub-records 0 --psnr-seconds 0"
 run() {  # rays steps warm flags...
@@ -10,9 +10,9 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'rays':$rays,'flags':'$*','ms_per_step':round(d['ms_per_step'],4),'sustained_ms':d['sustained'] and d['sustained']['ms_per_step'],'kernels':d['kernels_ms_per_step']}))" >> $OUT/ab.jsonl
 }
-for f in "" "--two-gathers" "--window4" "--xcd-pinned" "--split2x" "--xcd-pinned --split2x" "--separate-adam"; do run 1024 400 50 $f; done
-for r in 4096 16384; do for f in "" "--two-gathers" "--window4" "--xcd-pinned"; do run $r 100 10 $f; done; done
-for f in "" "--two-gathers" "--window4"; do run 65536 10 3 $f; done
-for f in "" "--two-gathers" "--window4"; do run 16384 10 3 --precision fp32 $f; done
-for f in "" "--two-gathers" "--xcd-pinned"; do run 1024 300 30 --precision fp32 $f; done
+for f in "" "--no-draw-ahead" "--bwd-one-wave"; do run 1024 400 50 $f; done
+for r in 128 256 512 2048 4096; do run $r 200 20; done
+run 16384 50 5
+run 65536 10 3
+run 1024 300 30 --precision fp32
 echo ab done
