@@ -202,15 +202,13 @@ def psnr_race(scan, n_rays, lr, precision="bf16", thresholds=(30.0, 35.0, 38.0),
     is evaluated between bursts of about `burst_s` seconds of training, so a reported time is an upper bound by at most one
     burst.  Also returns the sustained throughput over the whole race (rays / training seconds, >= 2 s unless the last
     threshold falls earlier)."""
-    from neuralvolumetricreconstructionformedicalimages_amd.dataset import DrawAhead
     device = scan.device
-    slots = [(torch.empty(n_rays, 8, device=device), torch.empty(n_rays, device=device)) for _ in range(2)]
-    ahead = DrawAhead(lambda k, slot: scan.sampler.draw(k, n_rays, slots[slot][0], slots[slot][1]), device)      # as in main()
+    rays = torch.empty(n_rays, 8, device=device)
     weight, loss_name = step_weights(n_rays, device)
 
     def run(engine, first, count):
         for i in range(first, first + count):
-            target, rays = ahead.get(i)
+            target, _ = scan.sampler.draw(i, n_rays, rays)
             engine.train_step(rays, target, weight, ray_base=i * n_rays)
 
     scratch = make_chest_engine(device, precision, lr, seed=seed)      # sizes the workspace, measures the step for the burst length
@@ -284,10 +282,7 @@ def main():
                          "stream, per-bucket Adam) with a world-size-1 process group")
     ap.add_argument("--dp-mode", choices=["sharded", "allreduce"], default="sharded",
                     help="N > 1: reduce-scatter -> per-rank Adam on a table slice -> all-gather (default), or all-reduce + replicated Adam")
-    ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,4-8,0-4 (the default)")
-    ap.add_argument("--no-draw-ahead", action="store_true",
-                    help="diagnostics: draw the pixels of step k inside step k on the main stream (default: the draw of step k + 1 runs "
-                         "on a side stream while step k computes -- dataset.DrawAhead, what train.py's loop does too)")
+    ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,0-8 (default: dist.default_bucket_levels -- one range below 2^20 points per step)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
@@ -342,7 +337,8 @@ def main():
                                  scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
                                  cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
                                            | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOW4 if args.window4 else 0) | (_abi.CFG_BACKWARD_ONE_WAVE_PER_SIMD if args.bwd_one_wave else 0) | (_abi.CFG_LEVELS_XCD_PINNED if args.xcd_pinned else 0),
-                                 bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode)
+                                 bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode,
+                                 rays_per_step_hint=args.rays)
 
     engine = make_engine(args.precision, pg)
     allreduce_bytes = engine.grad_flat.numel() * 4
@@ -352,19 +348,11 @@ def main():
     rays = torch.empty(n, 8, device=device)
     weight, loss_name = step_weights(n, device, world)               # N > 1: global mean over all ranks' rays
 
-    # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip).  The draw of
-    # step k + 1 is issued on a side stream before step k is enqueued (double-buffered), like a DataLoader that prefetches one item.
-    from neuralvolumetricreconstructionformedicalimages_amd.dataset import DrawAhead
-    ahead = None
-    if not args.no_draw_ahead:
-        slots = [(rays, torch.empty(n, device=device)), (torch.empty(n, 8, device=device), torch.empty(n, device=device))]
-        ahead = DrawAhead(lambda k, slot: sampler.draw(k, n, slots[slot][0], slots[slot][1]), device)
-
     def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
-        if eng is None and ahead is not None:
-            target, ray_buf = ahead.get(i)
-        else:
-            target, _ = sampler.draw(i, n_rays, ray_buf)
+        # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip).
+        # (Drawing step k + 1 on a side stream while step k computes was measured and is not done: the event waits that order the two
+        # streams cost more stream time than the 8 us launch they hide -- 0.3182 against 0.3118 ms per step.)
+        target, _ = sampler.draw(i, n_rays, ray_buf)
         return (eng or engine).train_step(ray_buf, target, w, ray_base=(i * world + rank) * n_rays)
 
     def barrier():
@@ -493,12 +481,12 @@ def main():
             if doc.get("csrc_fingerprint") != source_fingerprint():
                 traffic_note = (f"stale: the PMC passes ran on kernel sources {doc.get('csrc_fingerprint')}, this build is "
                                 f"{source_fingerprint()} -- rerun tools/collect_profiles.sh + tools/install_profiles.py")
-            elif n != doc.get("rays_per_step", 65536) or world != 1:
-                traffic_note = f"the PMC passes were taken at {doc.get('rays_per_step', 65536)} rays/step on one GPU"
+            elif str(n) not in doc.get("by_rays", {}) or world != 1:
+                traffic_note = f"the PMC passes were taken at {sorted(doc.get('by_rays', {}))} rays/step on one GPU"
             else:
-                traffic_table = doc.get(args.precision, {})
+                traffic_table = doc["by_rays"][str(n)].get(args.precision, {})
                 traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {doc.get('collected_at_commit')}, "
-                                f"kernel sources {doc.get('csrc_fingerprint')}")
+                                f"kernel sources {doc.get('csrc_fingerprint')}, {n} rays/step")
 
         def roof(kernel):
             """Roofline of ONE kernel: algorithmic bytes (or flops) of a launch / its average launch duration (HIP events on the

@@ -22,6 +22,7 @@
 #include "field_mlp.h"
 #include "field_mlp16.h"
 #include "fused_forward.h"
+#include "mlp_slabs.h"
 #include "scatter_binned.h"
 
 namespace naf {
@@ -339,20 +340,11 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
 
 // ---- 3: MLP backward --------------------------------------------------------------------------------------
 // slab layout == parameter block layout (kW0 .. kB3), one slab of kSlabStride floats per workgroup.
-constexpr uint32_t kSlabStride = 4352;
-constexpr uint32_t kSlabLoss = kMlpParams;         // slab entry behind the parameter block: the workgroup's share of the loss
-// ... and behind that the bit pattern of the workgroup's max |feature gradient| (the fixed-point scale of the binned scatter).  It
-// used to be one atomicMax per WAVE on a single word: same-address atomics retire one at a time (~12 ns each, MI355X_MICROARCH.md
-// "fanin"), 1 024 .. 3 072 of them were 12 .. 37 us of a 53 us kernel at 1 024 rays.  The slab reduction takes the maximum instead.
-constexpr uint32_t kSlabGmax = kMlpParams + 1u;
-
 // Training steps hand the backward kernels what the loss needs instead of a precomputed d loss / d acc: the masked squared error
 // of train.py:127 / loss.py:37 in weighted form, loss = sum_r w_r (acc_r - y_r)^2, d loss / d acc_r = 2 w_r (acc_r - y_r), is two
 // flops per ray -- a kernel launch of its own (loss_grad_kernel) cost a fortieth of the reference-size step.
 struct LossInputs { const float *acc, *target, *weight; };
-// ... and the reduction of the weight-gradient slabs applies the MLP's Adam update to the sums it has just formed
-// (naf_render_train_adam with mlp_param set) instead of writing them out for one more launch to read back.
-struct MlpAdam { float *param, *m, *v; AdamArgs a; };
+constexpr uint32_t kClearWords = 33;               // overflow counters of the binned scatter: total + one per level (Workspace::overflow)
 
 template <typename P>
 __device__ __forceinline__ void wave_lds_fence() {
@@ -365,8 +357,9 @@ template <typename P, uint32_t C>
 __global__ void __launch_bounds__(256)
 mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                     const float *__restrict__ grad_acc, LossInputs loss, typename P::feat_t::store_t *__restrict__ dfeat,
-                    float *__restrict__ slabs, uint32_t n_rays, uint32_t B, int act) {
+                    float *__restrict__ slabs, uint32_t n_rays, uint32_t B, int act, uint32_t *__restrict__ clear_words) {
     using Sh = MlpShared<P>;
+    if (clear_words != nullptr && blockIdx.x == 0u && threadIdx.x < kClearWords) clear_words[threadIdx.x] = 0u;      // see StepExtras
     using TR = typename P::tr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Sh::build(smem, mlp, 8);
@@ -538,8 +531,9 @@ mlp_backward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const 
 __global__ void __launch_bounds__(256, 3)                     // 168 VGPRs (11 spilled dwords): three waves per SIMD
 mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                       const float *__restrict__ grad_acc, LossInputs loss, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
-                      uint32_t n_rays, uint32_t B, int act, uint32_t parts) {
+                      uint32_t n_rays, uint32_t B, int act, uint32_t parts, uint32_t *__restrict__ clear_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (clear_words != nullptr && blockIdx.x == 0u && threadIdx.x < kClearWords) clear_words[threadIdx.x] = 0u;      // see StepExtras
     Mlp16Shared::build<8>(smem, mlp);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
     // wave-uniform values are made scalar explicitly: the ray record, its depths range and d acc then live in SGPRs
@@ -761,60 +755,12 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) slab[i] = red[i];
 }
 
-// ---- 5: slabs -> grad_mlp (+=) and loss (+=), summed in a fixed order (deterministic) ---------------------------------
-// 1024 threads = 32 entries x 32 slab groups: group g adds slabs g, g + 32, ... (four independent chains), the 32 partial sums are
-// combined through LDS in group order.  Entry kSlabLoss is the loss.  With `adam.param` set the finished sum of a parameter goes
-// straight into its Adam update (same expression as adam_kernel: adam_math.h) and the gradient buffer stays as it was.
-constexpr uint32_t kReduceParams = 32, kReduceGroups = 32;
-enum LossMode : int { kLossNone = 0, kLossAdd = 1, kLossAssign = 2 };       // loss_out[0] untouched / += / = the step's loss
+// ---- 5: slabs -> grad_mlp (+=), loss, gradient maximum: slab_reduce_block (mlp_slabs.h), as a launch of its own ----------------
+// (training steps on the binned scatter let spare workgroups of scatter_bin_kernel do it instead: run_binned_scatter)
 __global__ void __launch_bounds__(1024)
-mlp_grad_reduce_kernel(const float *__restrict__ slabs, uint32_t n_slabs, float *__restrict__ grad_mlp, float *__restrict__ loss_out,
-                       int loss_mode, MlpAdam adam, uint32_t *__restrict__ gmax_out, uint32_t *__restrict__ clear_words, uint32_t n_clear) {
+mlp_grad_reduce_kernel(SlabReduce sr) {
     __shared__ float part[kReduceGroups][kReduceParams];
-    // the overflow counters of the binned scatter that follows on the stream (one tiny launch less per step than a memset)
-    if (blockIdx.x == 0u && threadIdx.x < n_clear) clear_words[threadIdx.x] = 0u;
-    const uint32_t j = threadIdx.x % kReduceParams, g = threadIdx.x / kReduceParams;
-    const uint32_t i = blockIdx.x * kReduceParams + j;
-    if (i == kSlabGmax) {                                    // max |feature gradient| of the step: bit patterns, integer maximum
-        uint32_t m = 0u;
-        for (uint32_t k = g; k < n_slabs; k += kReduceGroups) m = max(m, __float_as_uint(slabs[(size_t)k * kSlabStride + i]));
-        part[g][j] = __uint_as_float(m);
-    } else {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        if (i <= kSlabLoss) {
-            uint32_t k = g;
-#pragma unroll 2
-            for (; k + 3u * kReduceGroups < n_slabs; k += 4u * kReduceGroups) {
-                s0 += slabs[(size_t)(k + 0u * kReduceGroups) * kSlabStride + i];
-                s1 += slabs[(size_t)(k + 1u * kReduceGroups) * kSlabStride + i];
-                s2 += slabs[(size_t)(k + 2u * kReduceGroups) * kSlabStride + i];
-                s3 += slabs[(size_t)(k + 3u * kReduceGroups) * kSlabStride + i];
-            }
-            for (; k < n_slabs; k += kReduceGroups) s0 += slabs[(size_t)k * kSlabStride + i];
-        }
-        part[g][j] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    if (g == 0 && i == kSlabGmax) {
-        uint32_t m = 0u;
-#pragma unroll
-        for (uint32_t q = 0; q < kReduceGroups; ++q) m = max(m, __float_as_uint(part[q][j]));
-        if (gmax_out != nullptr) *gmax_out = m;
-    } else if (g == 0 && i <= kSlabLoss) {
-        float total = 0.0f;
-#pragma unroll
-        for (uint32_t q = 0; q < kReduceGroups; ++q) total += part[q][j];
-        if (i == kSlabLoss) {
-            if (loss_mode != kLossNone && loss_out != nullptr) loss_out[0] = loss_mode == kLossAssign ? total : loss_out[0] + total;
-        }
-        else if (adam.param != nullptr) {
-            const float gsum = grad_mlp[i] + total;          // whatever the caller had accumulated there (+=), as adam_kernel would see it
-            float p = adam.param[i], m = adam.m[i], v = adam.v[i];
-            adam_one(p, m, v, gsum, adam.a);
-            adam.param[i] = p; adam.m[i] = m; adam.v[i] = v;
-            grad_mlp[i] = 0.0f;
-        } else grad_mlp[i] += total;
-    }
+    slab_reduce_block<kReduceGroups>(part, sr, blockIdx.x, threadIdx.x);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -1108,18 +1054,21 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
     return check_launch("mlp_forward_kernel");
 }
 
-// What a training step hands down so that its small clears ride on kernels it launches anyway: `clear_words` -- counters the slab
-// reduction zeroes (the overflow counters of the binned scatter); `loss_assign` -- loss_out[0] = loss instead of +=.
-struct StepExtras { uint32_t *clear_words; uint32_t n_clear; bool loss_assign; };
-constexpr StepExtras kNoExtras{nullptr, 0u, false};
+// What the backward pass hands down so that its small jobs ride on kernels it launches anyway: `clear_words` -- the overflow
+// counters of the binned scatter, zeroed by the MLP backward kernel (which always precedes the scatter on the stream; three memset
+// launches of ~5 us each were 4 % of the reference-size step); `loss_assign` -- loss_out[0] = loss instead of +=; `deferred` --
+// where to leave the description of the slab reduction instead of launching it (the first scatter_bin launch then runs it in spare
+// workgroups, beside its own: one dependent launch of ~11 us less per step).
+struct StepExtras { uint32_t *clear_words; bool loss_assign; SlabReduce *deferred; };
 
 static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad_mlp, float *loss_out, bool with_loss, const MlpAdam *madam,
                                uint32_t *gmax_bits, const StepExtras &ex, hipStream_t s) {
     const MlpAdam none{nullptr, nullptr, nullptr, AdamArgs{}};
+    const SlabReduce sr{slabs, n_slabs, grad_mlp, loss_out, !with_loss ? kLossNone : ex.loss_assign ? kLossAssign : kLossAdd,
+                        madam != nullptr ? *madam : none, gmax_bits};
+    if (ex.deferred != nullptr) { *ex.deferred = sr; return NAF_OK; }
     ProfScope prof_("mlp_grad_reduce_kernel", s);
-    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((kSlabGmax + 1u + kReduceParams - 1u) / kReduceParams), dim3(kReduceParams * kReduceGroups), 0, s,
-                       slabs, n_slabs, grad_mlp, loss_out, !with_loss ? kLossNone : ex.loss_assign ? kLossAssign : kLossAdd,
-                       madam != nullptr ? *madam : none, gmax_bits, ex.clear_words, ex.clear_words != nullptr ? ex.n_clear : 0u);
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(kSlabReduceBlocks), dim3(kReduceParams * kReduceGroups), 0, s, sr);
     return check_launch("mlp_grad_reduce_kernel");
 }
 
@@ -1142,7 +1091,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
             const uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(tiles, 12u), wave_goal / std::max<uint32_t>(n_rays, 1u)));
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays * parts + 3) / 4, kBackwardBlocks16));
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
-                               grad_acc, loss, (uint16_t *)dfeat, slabs, n_rays, B, cfg->last_activation, parts); }
+                               grad_acc, loss, (uint16_t *)dfeat, slabs, n_rays, B, cfg->last_activation, parts, ex.clear_words); }
             if (int rc = check_launch("mlp16_backward_kernel")) return rc;
             return run_mlp_grad_reduce(slabs, grid16, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
         }
@@ -1152,7 +1101,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     if (int rc = raise_lds_limit(kern, lds, "mlp_backward_kernel: cannot raise dynamic LDS limit")) return rc;      // fp32 images need > 64 KiB
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_rays + 3) / 4, kBackwardBlocks));
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc, loss,
-                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation); }
+                       (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation, ex.clear_words); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
     return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
 }
@@ -1174,7 +1123,7 @@ static bool adam_tail_possible(const naf_render_cfg *cfg, const Workspace &w) {
 template <typename P, uint32_t C, typename Rec>
 static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                               const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
-                              const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr) {
+                              const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
     using FT = typename P::feat_t;
     constexpr uint32_t NT = BinShape<Rec>::kThreads, PTS = BinShape<Rec>::kPoints;
     // levels per bin workgroup: all of them when there are enough tiles to fill the chip several times over (the sample
@@ -1202,11 +1151,16 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
     static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
     const bool per_level = per_level_launches(cfg);
-    // pass 1 over the levels [l0, l0 + nl): their records fill the region buffer from level slot 0
+    // pass 1 over the levels [l0, l0 + nl): their records fill the region buffer from level slot 0.  The first launch carries the
+    // reduction of the MLP backward's slabs when the caller deferred it (StepExtras): kSlabReduceBlocks workgroups behind the tiles.
+    SlabReduce job{};
+    if (slab_job != nullptr) job = *slab_job;
     auto launch_bin = [&](uint32_t l0, uint32_t nl) -> int {
         ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
-        hipLaunchKernelGGL(bin, dim3(plan.n_tiles, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const typename FT::store_t *)dfeat,
-                           offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan);
+        const uint32_t spare = job.slabs != nullptr ? kSlabReduceBlocks : 0u;
+        hipLaunchKernelGGL(bin, dim3(plan.n_tiles + spare, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const typename FT::store_t *)dfeat,
+                           offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job);
+        job = SlabReduce{};
         return check_launch("scatter_bin_kernel");
     };
     // pass 2 over the level slots [ly0, ly0 + nl) of a bin pass that started at level l0
@@ -1245,11 +1199,11 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                     const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
-                                    const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr) {
+                                    const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam);
-        return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam);
+        if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
+        return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
     }
     if (adam != nullptr) return fail(NAF_ERR_LAUNCH, "hash backward: the Adam tail needs the binned scatter");
     if (per_level_launches(cfg)) {
@@ -1272,9 +1226,9 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, bool overflow_cleared = false) {
-    if (w.binned && !overflow_cleared && hipMemsetAsync(w.overflow, 0, 33 * 4, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "binned scatter: memset failed");
-    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam);
+                             const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
+    // (the overflow counters were zeroed by the MLP backward kernel of this call: StepExtras)
+    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam, slab_job);
     if (adam != nullptr) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: the Adam tail cannot be combined with gradient buckets");
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
         return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
@@ -1364,15 +1318,18 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     // (a fused forward of the same cfg left no features behind unless it was asked to store them)
     if (!features_valid || (forward_fused(cfg) && (cfg->flags & NAF_CFG_FUSED_STORE_FEATURES) == 0u && !from_train))
         if (int rc = dispatch_encode<P, C>(src, emb, offsets, w.feat, B, cfg, s)) return rc;
-    // a training step's small clears ride on its own kernels: the slab reduction writes the gradient maximum and zeroes the
-    // overflow counters of the scatter (three memset launches of ~5 us each were 4 % of the reference-size step)
-    const StepExtras ex{w.binned ? w.overflow : nullptr, 33u, loss_assign};
+    // Single-GPU steps on the binned scatter defer the slab reduction (MLP gradient / Adam, loss, gradient maximum) to spare workgroups
+    // of the scatter's first launch; data-parallel steps need the MLP gradient final BEFORE the scatter (its all-reduce starts at
+    // `mlp_ready`), per-level diagnostics keep their launches apart.
+    SlabReduce job{};
+    const bool defer = w.binned && buckets == nullptr && !per_level_launches(cfg);
+    const StepExtras ex{w.binned ? w.overflow : nullptr, loss_assign, defer ? &job : nullptr};
     if (int rc = run_mlp_backward<P, C>(w.feat, mlp, src, grad_acc, loss, w.dfeat, w.slabs, w.binned ? w.gmax : nullptr, grad_mlp, loss_out, madam, n_rays, B, cfg,
-                                        from_train ? ex : kNoExtras, s)) return rc;
+                                        ex, s)) return rc;
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, from_train && w.binned);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, defer ? &job : nullptr);
 }
 
 template <typename P, uint32_t C>

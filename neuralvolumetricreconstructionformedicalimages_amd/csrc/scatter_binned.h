@@ -46,6 +46,7 @@
 #pragma once
 
 #include "adam_math.h"
+#include "mlp_slabs.h"
 #include "naf_device.h"
 
 namespace naf {
@@ -163,8 +164,16 @@ __global__ void __launch_bounds__(NT, NT >= 512u ? 4 : 2)       // 512 threads: 
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ blocks, uint32_t *__restrict__ runs,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
-                   BinPlan plan) {
+                   BinPlan plan, SlabReduce slab_job) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // Spare workgroups behind the tiles (first launch of a training step): the reduction of the MLP backward's weight-gradient
+    // slabs -- nothing in this kernel needs its results, the reducer that follows does (the gradient maximum), so it runs beside the
+    // tiles instead of as a dependent launch of its own in front of them.
+    if (blockIdx.x >= plan.n_tiles) {
+        if (blockIdx.y == 0u && slab_job.slabs != nullptr)
+            slab_reduce_block<NT / kReduceParams>(reinterpret_cast<float (*)[kReduceParams]>(smem), slab_job, blockIdx.x - plan.n_tiles, threadIdx.x);
+        return;
+    }
     constexpr uint32_t K = sizeof(Rec) / 4u;                    // dwords per record
     static_assert(PTS == 1u || PTS == 2u, "one or two points per thread");
     const uint32_t NB = 1u << plan.log2_nb, SLOTS = plan.slots;
@@ -414,8 +423,37 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     // between is latency-bound at small batches: issued here, the two overlap instead of following each other (1 024-ray step:
     // 0.131 -> see DESIGN.md 4.2).  rows_local * C <= 16 * 1024 by the LDS bound of the plan (make_bin_plan); whatever lies beyond is
     // loaded in the tail as before.
-    constexpr uint32_t kPre = (kAdam && C <= 2u) ? 16u : 0u;
+    // C == 2 (every shipped configuration): a thread owns QUADS of table elements -- two consecutive rows x two channels = 16
+    // contiguous bytes of param / m / v (rows 64 k .. 64 k + 63 of a bucket are consecutive table rows, see row_of) -- so the tail
+    // moves 16 bytes per lane and instruction like the stand-alone adam_kernel (6.2 TB/s) instead of 4 (the reducer with its
+    // element-wise tail: 522 MB in 0.137 ms = 3.8 TB/s at 1 024 rays).  Level offsets may be odd, i.e. the quads are only 8-byte
+    // aligned: gfx950 global accesses need dword alignment (Quad is declared with alignment 4, the compiler still emits dwordx4).
+    struct __attribute__((packed, aligned(4))) Quad { float x, y, z, w; };
+    constexpr uint32_t kPreQ = (kAdam && C == 2u) ? 4u : 0u;                 // quads prefetched per thread (16 elements)
+    constexpr uint32_t kPre = (kAdam && C == 1u) ? 16u : 0u;                 // other channel counts: element-wise
+    Quad preq_p[kPreQ ? kPreQ : 1u], preq_m[kPreQ ? kPreQ : 1u], preq_v[kPreQ ? kPreQ : 1u];
     float pre_p[kPre ? kPre : 1u], pre_m[kPre ? kPre : 1u], pre_v[kPre ? kPre : 1u];
+    const uint32_t n_quads = rows_local * C / 4u;                            // rows_local is a multiple of 64
+    // quad q holds local rows 2q, 2q + 1 (same 64-row block) = table rows row0, row0 + 1; a level with an odd row count (dense
+    // levels) ends with a quad whose second row does not exist: that one row is finished element-wise by its thread in the tail
+    auto quad_row = [&](uint32_t q) { return row_of(bucket, 2u * q, plan.log2_nb); };
+    if constexpr (kPreQ != 0u) {
+        const float *__restrict__ pp = adam.param + (size_t)off * C;
+        const float *__restrict__ pm = adam.m + (size_t)off * C;
+        const float *__restrict__ pv = adam.v + (size_t)off * C;
+#pragma unroll
+        for (uint32_t k = 0; k < kPreQ; ++k) {
+            const uint32_t q = threadIdx.x + k * T_;
+            const uint32_t row0 = quad_row(q);
+            preq_p[k] = preq_m[k] = preq_v[k] = Quad{0.0f, 0.0f, 0.0f, 0.0f};
+            if (q < n_quads && row0 + 1u < T) {
+                const size_t e = (size_t)row0 * C;
+                preq_p[k] = *reinterpret_cast<const Quad *>(pp + e);
+                preq_m[k] = *reinterpret_cast<const Quad *>(pm + e);
+                preq_v[k] = *reinterpret_cast<const Quad *>(pv + e);
+            }
+        }
+    }
     if constexpr (kPre != 0u) {
         const float *__restrict__ pp = adam.param + (size_t)off * C;
         const float *__restrict__ pm = adam.m + (size_t)off * C;
@@ -563,6 +601,68 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 else reinterpret_cast<uint16_t *>(adam.lp)[el] = f32_to_bf16(p);
             }
         };
+        if constexpr (kPreQ != 0u) {
+            // four elements at a time: e0 = (row0, ch 0), e1 = (row0, ch 1), e2 = (row0 + 1, ch 0), e3 = (row0 + 1, ch 1)
+            auto update4 = [&](uint32_t q, uint32_t row0, Quad p4, Quad m4, Quad v4) {
+                const uint32_t local0 = 2u * q;
+                const size_t e = (size_t)row0 * C;
+                const unsigned long long *a0 = &acc[0u * pitch + local0], *a1 = &acc[1u * pitch + local0];
+                float g[4] = {(float)ldexp((double)(long long)a0[0], -shift), (float)ldexp((double)(long long)a1[0], -shift),
+                              (float)ldexp((double)(long long)a0[1], -shift), (float)ldexp((double)(long long)a1[1], -shift)};
+                if (poison) g[0] = g[1] = g[2] = g[3] = nan;
+                if (spilled) {
+                    const Quad extra = *reinterpret_cast<const Quad *>(gg + e);
+                    const float x[4] = {extra.x, extra.y, extra.z, extra.w};
+                    bool any = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j)
+                        if (x[j] != 0.0f) { g[j] = x[j] + g[j]; any = true; }          // the order of the separate route: table += sum
+                    if (any) *reinterpret_cast<Quad *>(gg + e) = Quad{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) adam_one(p[j], m[j], v[j], g[j], adam.a);
+                *reinterpret_cast<Quad *>(pp + e) = Quad{p[0], p[1], p[2], p[3]};
+                *reinterpret_cast<Quad *>(pm + e) = Quad{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<Quad *>(pv + e) = Quad{v[0], v[1], v[2], v[3]};
+                if (adam.lp != nullptr) {
+                    struct __attribute__((packed, aligned(4))) Half4 { uint32_t lo, hi; };
+                    const size_t el = (size_t)off * C + e;
+                    Half4 h;
+                    if (adam.lp_dtype == kAdamLpF16) {
+                        const _Float16 h0 = (_Float16)p[0], h1 = (_Float16)p[1], h2 = (_Float16)p[2], h3 = (_Float16)p[3];
+                        h.lo = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                        h.hi = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+                    } else {
+                        h.lo = (uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16);
+                        h.hi = (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16);
+                    }
+                    *reinterpret_cast<Half4 *>(reinterpret_cast<uint16_t *>(adam.lp) + el) = h;
+                }
+            };
+            auto finish = [&](uint32_t q, bool prefetched, const Quad &p4, const Quad &m4, const Quad &v4) {
+                if (q >= n_quads) return;
+                const uint32_t row0 = quad_row(q);
+                if (row0 + 1u < T) {
+                    if (prefetched) update4(q, row0, p4, m4, v4);
+                    else {
+                        const size_t e = (size_t)row0 * C;
+                        update4(q, row0, *reinterpret_cast<const Quad *>(pp + e), *reinterpret_cast<const Quad *>(pm + e),
+                                *reinterpret_cast<const Quad *>(pv + e));
+                    }
+                } else if (row0 < T) {                       // the level's last row when its row count is odd
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) {
+                        const size_t e = (size_t)row0 * C + ch;
+                        update(2u * q, ch, row0, pp[e], pm[e], pv[e]);
+                    }
+                }
+            };
+#pragma unroll
+            for (uint32_t k = 0; k < kPreQ; ++k) finish(threadIdx.x + k * T_, true, preq_p[k], preq_m[k], preq_v[k]);
+            const Quad none{0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t q = threadIdx.x + kPreQ * T_; q < n_quads; q += T_) finish(q, false, none, none, none);
+        } else {
         if constexpr (kPre != 0u) {
 #pragma unroll
             for (uint32_t k = 0; k < kPre; ++k) {
@@ -581,9 +681,29 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 update(local, ch, row, pp[e], pm[e], pv[e]);
             }
         }
+        }
     } else if (gridDim.z == 1u) {
         // sole owner, and the bucket's local rows 64 k .. 64 k + 63 are 64 consecutive table rows: add the sums in place,
         // coalesced (64 x C floats per block)
+        if constexpr (C == 2u) {                             // 16 bytes per lane, like the Adam tail above
+            for (uint32_t q = threadIdx.x; q < n_quads; q += T_) {
+                const uint32_t row0 = quad_row(q), local0 = 2u * q;
+                const unsigned long long *a0 = &acc[0u * pitch + local0], *a1 = &acc[1u * pitch + local0];
+                if (row0 + 1u < T) {
+                    Quad *dst = reinterpret_cast<Quad *>(gg + (size_t)row0 * C);
+                    const Quad old = *dst;
+                    Quad sum;
+                    sum.x = old.x + (poison ? nan : (float)ldexp((double)(long long)a0[0], -shift));
+                    sum.y = old.y + (poison ? nan : (float)ldexp((double)(long long)a1[0], -shift));
+                    sum.z = old.z + (poison ? nan : (float)ldexp((double)(long long)a0[1], -shift));
+                    sum.w = old.w + (poison ? nan : (float)ldexp((double)(long long)a1[1], -shift));
+                    *dst = sum;
+                } else if (row0 < T) {
+                    gg[(size_t)row0 * C] += poison ? nan : (float)ldexp((double)(long long)a0[0], -shift);
+                    gg[(size_t)row0 * C + 1u] += poison ? nan : (float)ldexp((double)(long long)a1[0], -shift);
+                }
+            }
+        } else
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
             const uint32_t row = row_of(bucket, local, plan.log2_nb);

@@ -171,45 +171,6 @@ class TIGREDataset(Dataset):
         return {"projs": self.projs[index], "rays": self.rays[index]}
 
 
-class DrawAhead:
-    """Double-buffered producer on a side HIP stream: while the consumer's step k computes, item k + 1 is drawn (the pixel draw,
-    target gather and ray generation of `naf_draw_scan_rays` are one small launch that needs nothing of step k) -- what the
-    reference gets from its DataLoader workers, without a host round trip.  `produce(k, slot)` runs under the side stream and
-    returns the item (device tensors; `slot` in {0, 1} names the buffer pair it may write into).  The consumer calls `get(k)`
-    once per step, in order; its work on item k must be enqueued on the current stream before it asks for item k + 1."""
-
-    def __init__(self, produce, device):
-        self.produce = produce
-        self.device = torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device)
-        self.side.wait_stream(torch.cuda.current_stream(self.device))      # whatever the items are drawn from is resident
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.free = [torch.cuda.Event(), torch.cuda.Event()]
-        self.items, self.index, self.used = [None, None], [None, None], [False, False]
-
-    def _launch(self, k):
-        slot = k & 1
-        if self.used[slot]:                               # the step that read this slot's previous item has been enqueued
-            self.side.wait_event(self.free[slot])
-        with torch.cuda.stream(self.side):
-            self.items[slot] = self.produce(k, slot)
-            self.ready[slot].record(self.side)
-        self.index[slot], self.used[slot] = k, False
-
-    def get(self, k, ahead=True):
-        main = torch.cuda.current_stream(self.device)
-        slot, other = k & 1, (k & 1) ^ 1
-        if self.index[slot] != k:                         # first item, or an access out of order
-            self._launch(k)
-        if ahead:
-            if self.used[other]:                          # item k - 1 was consumed: its step is on the stream by now
-                self.free[other].record(main)
-            self._launch(k + 1)
-        main.wait_event(self.ready[slot])
-        self.used[slot] = True
-        return self.items[slot]
-
-
 def synthetic_scan(n_voxel=64, n_train=50, n_val=8, mode="cone", tilt_angle=0, seed=0, device="cpu", full_proj=False,
                    geometry=None, train_angles=None):
     """A complete in-memory scan with the pickle schema, from the analytic phantom (no data ships with the reference).

@@ -63,8 +63,14 @@ def global_mean_weights(mask, group=None):
     return m / total.clamp(min=1.0)
 
 
-def default_bucket_levels(num_levels):
-    """Level ranges in the order the gradient scatter finishes them: the fine half, then the coarse half.
+# Below this many sample points per rank and step (the reference's 1 024 rays x 192 samples are 0.2 M) the scatter of half the
+# levels lasts ~0.06 ms -- less than the launch latency of the collective it would hide -- so the table is exchanged as ONE range:
+# three collectives per step (MLP all-reduce, reduce-scatter, all-gather) instead of five, one reducer launch instead of two.
+SINGLE_BUCKET_BELOW_POINTS = 1 << 20
+
+
+def default_bucket_levels(num_levels, points_per_step=None):
+    """Level ranges in the order the gradient scatter finishes them: the fine half, then the coarse half (one range for small steps).
     Two buckets of L/2 levels keep every reducer launch UNSPLIT (64 row buckets x 8 levels = 512 workgroups: a workgroup is the
     sole owner of its rows and adds its 64-bit fixed-point sums in a fixed order), so the table gradient a rank hands to the
     exchange is bit-reproducible from run to run.  Buckets of four levels or fewer (round 2's default had two of them) split each
@@ -74,6 +80,8 @@ def default_bucket_levels(num_levels):
     all-reduce left anyway.  Measured on one GPU (bench.py --force-dp --buckets ...): 9.13-9.15 ms per 65 536-ray step for the
     two halves against 9.08-9.18 ms for three buckets."""
     L = int(num_levels)
+    if points_per_step is not None and int(points_per_step) < SINGLE_BUCKET_BELOW_POINTS:
+        return [(0, L)]
     return [(L // 2, L), (0, L // 2)] if L >= 2 else [(0, L)]
 
 

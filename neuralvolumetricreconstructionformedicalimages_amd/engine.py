@@ -25,7 +25,7 @@ from . import fused
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
                  mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384, scatter_mode=None, cfg_flags=None,
-                 bucket_levels=None, fuse_table_adam=True, dp_mode="sharded"):
+                 bucket_levels=None, fuse_table_adam=True, dp_mode="sharded", rays_per_step_hint=None):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -98,7 +98,7 @@ class NAFEngine:
             if int(n_streams) > 1:
                 raise ValueError("NAFEngine: n_streams > 1 cannot be combined with a process group (the bucket events are "
                                  "recorded by the one launch that owns the gradient buffer)")
-            self._init_data_parallel(bucket_levels)
+            self._init_data_parallel(bucket_levels, None if rays_per_step_hint is None else int(rays_per_step_hint) * self.n_samples)
         self.n_streams = max(1, int(n_streams))
         self.chunk_rays = int(chunk_rays)
         self._lanes = []
@@ -107,12 +107,13 @@ class NAFEngine:
                                 "mlp_g": torch.zeros_like(self.mlp), "loss": torch.zeros(1, device=dev), "ws": None})
 
     # ---- data parallel -------------------------------------------------------------------------------------
-    def _init_data_parallel(self, bucket_levels):
-        """Buckets = level ranges in the order the scatter finishes them (dist.default_bucket_levels)."""
+    def _init_data_parallel(self, bucket_levels, points_per_step=None):
+        """Buckets = level ranges in the order the scatter finishes them (dist.default_bucket_levels; `points_per_step`, this
+        rank's sample points per step when the caller knows them, picks the single-range exchange for small steps)."""
         from . import dist as naf_dist
         L = self.net.encoder.num_levels
         if bucket_levels is None:
-            bucket_levels = naf_dist.default_bucket_levels(L)
+            bucket_levels = naf_dist.default_bucket_levels(L, points_per_step)
         bucket_levels = [(int(a), int(b)) for a, b in bucket_levels]
         if len(bucket_levels) > _abi.MAX_GRAD_BUCKETS:
             raise ValueError(f"at most {_abi.MAX_GRAD_BUCKETS} gradient buckets")

@@ -26,9 +26,13 @@ def _bump(device):
 
 _default_scatter_mode = _abi.SCATTER_AUTO
 _default_flags = 0
-# forward-only calls (projection render, volume query) run gathers + MLP in one kernel where the shape allows it; set False to
-# take the two-kernel path (same bits)
-forward_fused = True
+# True: forward-only calls (projection render, volume query) run gathers + MLP in ONE kernel where the shape allows it
+# (NAF_CFG_FORWARD_FUSED; same bits, no workspace).  Off by default because it is slower -- measured on MI355X
+# (profiles/round3_eval_fused_vs_two_kernels.jsonl): 512 x 512 projection 34.2 ms fused against 12.3 ms with encode_kernel +
+# mlp16_forward_kernel, 256^3 grid query 5.0 against 3.4 ms.  A kernel that walks all 16 levels of a tile has the whole table as
+# its working set: 62 GB of fabric fetches per call against 0.3 GB for the level-major encoder, whose level stays in L2; the
+# feature round trip it avoids is 0.2 ms of that.
+forward_fused = False
 
 
 @contextlib.contextmanager

@@ -102,7 +102,6 @@ class Trainer:
         self.loss_mode = backend.get("loss", "chunk_sum")
         self.i_log = int(cfg["log"].get("i_log", 100))      # steps between train/loss scalars (reading the loss synchronises)
         self._plain_weights = {}
-        self._draw_ahead = None
         self._even_shards = cfg["train"]["n_rays"] % max(self.world, 1) == 0     # every rank then holds n_rays / world rays
 
         self.expdir = osp.join(cfg["exp"]["expdir"], cfg["exp"]["expname"])
@@ -140,7 +139,8 @@ class Trainer:
         if want_fused and noise_free and self.n_fine == 0 and self.net.fused_supported() and self.device.type == "cuda":
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
-                                    table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group)
+                                    table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group,
+                                    rays_per_step_hint=-(-int(cfg["train"]["n_rays"]) // max(self.world, 1)))
             self.engine.broadcast_parameters()
             self.optimizer = _EngineOptimizer(self.engine)
         elif self.group is not None:
@@ -227,20 +227,9 @@ class Trainer:
         whose items already are whole ray batches (trainer.py:32-37); with the fused engine the items are consumed directly --
         the collate step would only copy every tensor once more to add a batch dimension of one."""
         if self.engine is not None and self.conf["train"]["n_batch"] == 1:
-            return self._items_drawn_ahead()
+            dset = self.train_dset
+            return (dset[i] for i in range(len(dset)))
         return iter(self.train_dloader)
-
-    def _items_drawn_ahead(self):
-        """The items of one epoch, each drawn on a side stream while the previous step computes (dataset.DrawAhead): the draw is
-        one small launch that depends on nothing the step produces.  Items are numbered over the whole run (item k is
-        dataset[k % len]), so the keyed pixel draws follow the same sequence with and without the look-ahead."""
-        dset = self.train_dset
-        if self._draw_ahead is None:
-            from .dataset import DrawAhead
-            self._draw_ahead = DrawAhead(lambda k, slot: dset[k % len(dset)], self.device)
-        first = self.global_step                              # items consumed so far (resume included)
-        for i in range(len(dset)):
-            yield self._draw_ahead.get(first + i)
 
     def save_checkpoint(self, idx_epoch):
         if self.rank != 0:                                 # replicas are identical; rank 0 writes

@@ -8,30 +8,35 @@ set -e
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--steps 10 --warmup 2 --rays 65536 --cpu-seconds 0 --sub-records 0"
-PMC="--steps 3 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-echo stats done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py $PMC > $OUT/bench_fetch.json 2> $OUT/fetch.err
-echo fetch done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 bench.py $PMC > $OUT/bench_write.json 2> $OUT/write.err
+COMMON="--cpu-seconds 0 --sub-records 0 --psnr-seconds 0"
+# the bench's default workload (chest_50.yaml's own step: 1 024 rays) and the throughput end of the batch curve (65 536 rays)
+for R in 1024 65536; do
+  if [ $R = 1024 ]; then ARGS="--steps 200 --warmup 20 --rays $R $COMMON"; PMC="--steps 50 --warmup 10 --rays $R $COMMON"; else ARGS="--steps 10 --warmup 2 --rays $R $COMMON"; PMC="--steps 3 --warmup 1 --rays $R $COMMON"; fi
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -o stats -- python3 bench.py $ARGS > $OUT/bench_under_rocprof_$R.json 2> $OUT/stats_$R.err
+  echo stats $R done
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$R -o fetch -- python3 bench.py $PMC > $OUT/bench_fetch_$R.json 2> $OUT/fetch_$R.err
+  echo fetch $R done
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$R -o write -- python3 bench.py $PMC > $OUT/bench_write_$R.json 2> $OUT/write_$R.err
+done
+ARGS="--steps 10 --warmup 2 --rays 65536 $COMMON"
+PMC="--steps 3 --warmup 1 --rays 65536 $COMMON"
 echo write done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/mfma -o mfma -- python3 bench.py $PMC > $OUT/bench_mfma.json 2> $OUT/mfma.err
 echo mfma done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0 > $OUT/bench_sqa.json 2> $OUT/sqa.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0 --sub-records 0 > $OUT/bench_sqb.json 2> $OUT/sqb.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 $COMMON > $OUT/bench_sqa.json 2> $OUT/sqa.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 $COMMON > $OUT/bench_sqb.json 2> $OUT/sqb.err
 echo sq done
 timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo default done
-for r in 128 1024 4096 16384 65536 262144 1048576; do
-  timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays $r --cpu-seconds 0 --sub-records 0 >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
+for r in 128 256 512 1024 2048 4096 16384 65536 262144 1048576; do
+  timeout -k 10 300 python bench.py --steps 20 --warmup 5 --rays $r $COMMON >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
 done
 echo sweep done
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 --cpu-seconds 0 --sub-records 0 > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
-timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 --cpu-seconds 0 --sub-records 0 > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
-timeout -k 10 300 python bench.py --force-dp --steps 10 --warmup 3 --cpu-seconds 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 $COMMON > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
+timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 $COMMON > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
+timeout -k 10 300 python bench.py --force-dp --steps 200 --warmup 20 --cpu-seconds 0 --psnr-seconds 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
 # the encoder with all levels of a point tile in flight at once (what a single fused gather+MLP kernel would do to the caches)
-timeout -k 10 300 python bench.py --interleaved-levels --steps 10 --warmup 3 --cpu-seconds 0 --sub-records 0 > $OUT/bench_interleaved.json 2> $OUT/interleaved.err
+timeout -k 10 300 python bench.py --interleaved-levels --rays 65536 --steps 10 --warmup 3 $COMMON > $OUT/bench_interleaved.json 2> $OUT/interleaved.err
 echo modes done
 timeout -k 10 200 python tools/eval_bench.py > $OUT/eval.jsonl 2> $OUT/eval.err
 timeout -k 10 200 python tools/eval_bench.py --precision fp32 >> $OUT/eval.jsonl 2>> $OUT/eval.err
@@ -52,6 +57,6 @@ timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-e
 timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-every 5000 --out $OUT/psnr_1024_bf16.json > $OUT/psnr_c.log 2>&1
 echo all done
 # summarise on the box and keep only the summaries (the kernel traces alone exceed what gpurun copies back)
-NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round2}
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/sqa $OUT/sqb $OUT/t22_fp16 $OUT/t22_fp32
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3}
+rm -rf $OUT/stats_1024 $OUT/stats_65536 $OUT/fetch_1024 $OUT/fetch_65536 $OUT/write_1024 $OUT/write_65536 $OUT/mfma $OUT/sqa $OUT/sqb $OUT/t22_fp16 $OUT/t22_fp32
 ls gpurun_out/profiles_staged

@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
 DST = os.environ.get("NAF_PROFILES_DST", os.path.join(REPO, "profiles"))      # the GPU box stages into gpurun_out/ (no 64 MiB of traces)
 os.makedirs(DST, exist_ok=True)
-TAG = sys.argv[1] if len(sys.argv) > 1 else "round2"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "round3"
 
 
 def copy(src, dst):
@@ -19,8 +19,14 @@ def copy(src, dst):
     print("profiles/" + dst)
 
 
-copy("stats/stats_kernel_stats.csv", f"{TAG}_kernel_stats_bf16_65536rays.csv")
-copy("bench_under_rocprof.json", f"{TAG}_bench_under_rocprof.json")
+import glob  # noqa: E402
+
+for R in (1024, 65536):
+    hits = glob.glob(os.path.join(SRC, f"stats_{R}", "**", "*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copyfile(hits[0], os.path.join(DST, f"{TAG}_kernel_stats_bf16_{R}rays.csv"))
+        print(f"profiles/{TAG}_kernel_stats_bf16_{R}rays.csv")
+    copy(f"bench_under_rocprof_{R}.json", f"{TAG}_bench_under_rocprof_{R}rays.json")
 copy("bench_default.json", f"{TAG}_bench_default.json")
 copy("batch_sweep.jsonl", f"{TAG}_batch_sweep.jsonl")
 copy("bench_fp32_16384.json", f"{TAG}_bench_fp32_16384rays.json")
@@ -32,36 +38,39 @@ for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"
     if os.path.exists(os.path.join(SRC, src)):
         copy(src, f"{TAG}_{dst}")
 
-per_dispatch = os.path.join(DST, f"{TAG}_pmc_bytes_per_dispatch.json")
-subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"),
-                os.path.join(SRC, "fetch", "fetch_counter_collection.csv"),
-                os.path.join(SRC, "write", "write_counter_collection.csv"), "--json", per_dispatch], check=True)
-pd = json.load(open(per_dispatch))
-
-
-def hbm(kernel):   # MI355X_MICROARCH.md: value * 1024 (done by pmc_summary), FETCH_SIZE doubled on gfx950 for wide reads
-    row = pd.get(kernel, {})
-    return 2.0 * row.get("FETCH_SIZE", 0.0) + row.get("WRITE_SIZE", 0.0)
-
-
 sys.path.insert(0, REPO)
 from neuralvolumetricreconstructionformedicalimages_amd.build import source_fingerprint  # noqa: E402
 
+# HBM-side bytes per launch of every kernel of the step, per batch size.  MI355X_MICROARCH.md: value * 1024 (done by pmc_summary),
+# FETCH_SIZE doubled on gfx950 (it tallies 64 B per fabric read request, and a streamed line is one 128-byte request;
+# profiles/round3_cache_counters.md shows the calibration: exact for scattered single-sector gathers, half for whole lines --
+# every kernel of this step streams whole lines except the encoder, whose fetches are 1 % of its traffic at T = 2^19).
+# Keys are the names bench.py's profiler uses (naf_profile_collect): the 16-point MFMA kernels report under the generic names.
+ALIAS = {"mlp16_forward_kernel": "mlp_forward_kernel", "mlp16_backward_kernel": "mlp_backward_kernel"}
+by_rays = {}
+for R in (1024, 65536):
+    fetch = glob.glob(os.path.join(SRC, f"fetch_{R}", "**", "*counter_collection.csv"), recursive=True)
+    write = glob.glob(os.path.join(SRC, f"write_{R}", "**", "*counter_collection.csv"), recursive=True)
+    if not (fetch and write):
+        continue
+    per_dispatch = os.path.join(DST, f"{TAG}_pmc_bytes_per_dispatch_{R}rays.json")
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"), fetch[0], write[0], "--json", per_dispatch], check=True)
+    pd = json.load(open(per_dispatch))
+    table = {}
+    for k, row in pd.items():
+        name = ALIAS.get(k, k)
+        table[name] = table.get(name, 0.0) + 2.0 * row.get("FETCH_SIZE", 0.0) + row.get("WRITE_SIZE", 0.0)
+    by_rays[str(R)] = {"bf16": table}
 traffic = {
     "csrc_fingerprint": source_fingerprint(),      # bench.py prints these figures only while the kernel sources are unchanged
     "collected_at_commit": os.environ.get("NAF_COMMIT") or subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
-    "_comment": "HBM-side bytes per training step (65536 rays, 12.58 M points) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                "(separate runs), value*1024, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; per-dispatch "
-                f"figures in profiles/{TAG}_pmc_bytes_per_dispatch.json, calibration notes in DESIGN.md section 5",
-    "bf16": {
-        "hash_forward": hbm("encode_kernel"),
-        "hash_backward": hbm("scatter_bin_kernel") + hbm("scatter_reduce_kernel"),
-        "mlp_forward": hbm("mlp_forward_kernel") + hbm("mlp16_forward_kernel"),
-        "mlp_backward": hbm("mlp_backward_kernel") + hbm("mlp16_backward_kernel"),
-    },
+    "_comment": "HBM-side bytes per LAUNCH and kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of "
+                "`python3 bench.py --rays R`, value*1024, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; per-dispatch "
+                f"figures in profiles/{TAG}_pmc_bytes_per_dispatch_<R>rays.json, calibration in profiles/round3_cache_counters.md",
+    "by_rays": by_rays,
 }
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
-print("profiles/pmc_traffic.json", {k: round(v / 1e9, 2) for k, v in traffic["bf16"].items()})
+print("profiles/pmc_traffic.json", {r: {k: round(v / 1e6, 1) for k, v in t["bf16"].items()} for r, t in by_rays.items()})
 
 
 # ---- T = 2^22: HBM bytes fetched by the fused forward's encoder ----------------------------------------------------------

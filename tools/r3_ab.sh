@@ -10,9 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'rays':$rays,'flags':'$*','ms_per_step':round(d['ms_per_step'],4),'sustained_ms':d['sustained'] and d['sustained']['ms_per_step'],'kernels':d['kernels_ms_per_step']}))" >> $OUT/ab.jsonl
 }
-for f in "" "--no-draw-ahead" "--bwd-one-wave"; do run 1024 400 50 $f; done
-for r in 128 256 512 2048 4096; do run $r 200 20; done
-run 16384 50 5
-run 65536 10 3
+for f in "" "--bwd-one-wave" "--force-dp"; do run 1024 400 50 $f; done
+for r in 256 4096 65536; do run $r 50 5; done
 run 1024 300 30 --precision fp32
 echo ab done
