@@ -470,12 +470,24 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
             }
         }
     }
-    for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
-    __syncthreads();
-
     // the wave index is made scalar explicitly: tile ranges, run-word addresses and block bases then live in SGPRs
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = T_ >> 6;
     const size_t run0 = run_index(plan, ly, bucket, 0);
+    // every wave streams ONE contiguous range of tiles
+    // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
+    const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
+    const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
+    // (in whole 64-tile blocks when there are that many; a 1 024-ray step has 192 tiles, and 64-tile blocks would leave 13 of
+    // the 16 waves without work: 0.136 -> 0.1 ms)
+    const uint32_t share = (split_tiles + n_waves - 1u) / n_waves;
+    const uint32_t per_wave = share >= 64u ? (share + 63u) & ~63u : (share + 7u) & ~7u;
+    const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
+    // the run words of the wave's first 64 tiles are requested here, with the Adam operands and in front of the clear and its
+    // barrier: the record phase then starts with ONE dependent round trip (run words -> records) less on its critical path
+    const uint32_t first_runs = t_begin + lane < t_end ? runs[run0 + t_begin + lane] : 0u;
+    for (uint32_t i = threadIdx.x; i < pitch * C; i += T_) acc[i] = 0ull;
+    __syncthreads();
+
     auto add = [&](const Rec &r) {          // both halves unconditionally: a record without a second corner adds zeros to its own row
         const uint32_t la = r.w[0] & 0xffffu, lb = la ^ (r.w[0] >> 16);
 #pragma unroll
@@ -489,22 +501,13 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     // flight per lane before the first LDS atomic (lanes past a run's end read its first record, a line that is fetched
     // anyway -> no extra traffic); whatever a run holds beyond 64 + kTail records follows in a plain loop.
     constexpr uint32_t kGroup = sizeof(Rec) <= 12 ? 8u : 4u, kTail = 32;
-    // every wave streams ONE contiguous range of tiles
-    // gridDim.z > 1 (few levels per pass at very large batches): the tiles are split between gridDim.z workgroups
-    const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
-    const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
-    // (in whole 64-tile blocks when there are that many; a 1 024-ray step has 192 tiles, and 64-tile blocks would leave 13 of
-    // the 16 waves without work: 0.136 -> 0.1 ms)
-    const uint32_t share = (split_tiles + n_waves - 1u) / n_waves;
-    const uint32_t per_wave = share >= 64u ? (share + 63u) & ~63u : (share + 7u) & ~7u;
-    const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
     if (plan.log2_w < 6u) {
         // Many buckets (T >= 2^20: 128 .. 512 per level) make the runs short -- 8 to 32 records: a wave takes G = 64 / W runs per
         // instruction, W lanes each, four instructions' worth of loads in flight; whatever a run holds beyond W follows in a loop.
         const uint32_t W = 1u << plan.log2_w, G = 64u >> plan.log2_w, g = lane >> plan.log2_w, j = lane & (W - 1u);
         constexpr uint32_t kSteps = 4;
         for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
-            const uint32_t mine = t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u;
+            const uint32_t mine = t0 == t_begin ? first_runs : (t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u);
             const uint32_t n_here = min(64u, t_end - t0);
             for (uint32_t s0 = 0; s0 < n_here; s0 += kSteps * G) {
                 uint32_t n4[kSteps];
@@ -529,7 +532,7 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
         }
     } else
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
-        const uint32_t mine = t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u;
+        const uint32_t mine = t0 == t_begin ? first_runs : (t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u);
         const uint32_t n_here = min(64u, t_end - t0);
         for (uint32_t j = 0; j < n_here; j += kGroup) {
             uint32_t n[kGroup], n_max = 0u;

@@ -4,10 +4,13 @@
 #   sweep, the fp32 mode, the per-level split, the data-parallel step on one GPU, evaluation and train.py throughput,
 #   other BASELINE shapes and the chest PSNR curves.  Everything lands in gpurun_out/prof/; tools/install_profiles.py copies
 #   the summaries into profiles/.
+# Two parts, one gpurun call each (a call is capped at 20 minutes):  bash tools/collect_profiles.sh A   /   ... B
 set -e
 export TMPDIR=/tmp
+PART=${1:-A}
 OUT=gpurun_out/prof
-rm -rf $OUT && mkdir -p $OUT
+mkdir -p $OUT
+if [ "$PART" = A ]; then
 COMMON="--cpu-seconds 0 --sub-records 0 --psnr-seconds 0"
 # the bench's default workload (chest_50.yaml's own step: 1 024 rays) and the throughput end of the batch curve (65 536 rays)
 for R in 1024 65536; do
@@ -26,6 +29,9 @@ echo mfma done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqa -o sqa -- python3 bench.py --steps 2 --warmup 1 --rays 65536 $COMMON > $OUT/bench_sqa.json 2> $OUT/sqa.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 $COMMON > $OUT/bench_sqb.json 2> $OUT/sqb.err
 echo sq done
+# the counter passes are in: derive profiles/pmc_traffic.json now, so that the default line below carries `roofline.traffic`
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3} > $OUT/install_a.log 2>&1
+cp gpurun_out/profiles_staged/pmc_traffic.json profiles/pmc_traffic.json
 timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo default done
 for r in 128 256 512 1024 2048 4096 16384 65536 262144 1048576; do
@@ -38,8 +44,16 @@ timeout -k 10 300 python bench.py --force-dp --steps 200 --warmup 20 --cpu-secon
 # the encoder with all levels of a point tile in flight at once (what a single fused gather+MLP kernel would do to the caches)
 timeout -k 10 300 python bench.py --interleaved-levels --rays 65536 --steps 10 --warmup 3 $COMMON > $OUT/bench_interleaved.json 2> $OUT/interleaved.err
 echo modes done
-timeout -k 10 200 python tools/eval_bench.py > $OUT/eval.jsonl 2> $OUT/eval.err
-timeout -k 10 200 python tools/eval_bench.py --precision fp32 >> $OUT/eval.jsonl 2>> $OUT/eval.err
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3}
+rm -rf $OUT/stats_1024 $OUT/stats_65536 $OUT/fetch_1024 $OUT/fetch_65536 $OUT/write_1024 $OUT/write_65536 $OUT/mfma $OUT/sqa $OUT/sqb
+ls gpurun_out/profiles_staged
+exit 0
+fi
+# ---- part B: evaluation side, train.py loop, other BASELINE shapes, T = 2^22 fetch bytes, PSNR curves and the time-to-PSNR grid ----
+rm -f $OUT/eval.jsonl $OUT/shapes.jsonl $OUT/psnr_race_grid.jsonl
+for f in "" "--precision fp32" "--fused" "--fused --store-features"; do
+  timeout -k 10 200 python tools/eval_bench.py $f >> $OUT/eval.jsonl 2>> $OUT/eval.err
+done
 timeout -k 10 300 python tools/train_throughput.py 2> $OUT/train_py.err | grep "^{" | tail -n 1 > $OUT/train_py.json
 for a in "--log2T 22 --samples 320 --table fp16 --rays 32768" "--log2T 21 --samples 192 --table bf16 --rays 32768" "--log2T 20 --samples 192 --table bf16 --rays 65536" "--log2T 19 --samples 576 --table bf16 --rays 16384" "--log2T 19 --samples 192 --table bf16 --rays 65536"; do
   timeout -k 10 100 python tools/step_bench.py $a 2>> $OUT/shapes.err | tail -n 1 >> $OUT/shapes.jsonl
@@ -55,8 +69,10 @@ echo T22 fetch done
 timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --out $OUT/psnr_16384_bf16.json > $OUT/psnr_a.log 2>&1
 timeout -k 10 300 python tools/train_chest.py --rays 16384 --steps 2500 --eval-every 500 --precision fp32 --out $OUT/psnr_16384_fp32.json > $OUT/psnr_b.log 2>&1
 timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-every 5000 --out $OUT/psnr_1024_bf16.json > $OUT/psnr_c.log 2>&1
+# time to 30 / 35 / 38 dB volume PSNR per operating point (rays per step : learning rate); 1024:1e-3 is the reference's own
+timeout -k 10 400 python tools/psnr_race.py --configs 256:2e-3,512:2e-3,512:4e-3,1024:1e-3,1024:2e-3,1024:4e-3,1024:8e-3,2048:4e-3,4096:4e-3,16384:4e-3,65536:8e-3 --max-train-s 10 --out $OUT/psnr_race_grid.jsonl > $OUT/race.log 2>&1
 echo all done
 # summarise on the box and keep only the summaries (the kernel traces alone exceed what gpurun copies back)
 NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3}
-rm -rf $OUT/stats_1024 $OUT/stats_65536 $OUT/fetch_1024 $OUT/fetch_65536 $OUT/write_1024 $OUT/write_65536 $OUT/mfma $OUT/sqa $OUT/sqb $OUT/t22_fp16 $OUT/t22_fp32
+rm -rf $OUT/t22_fp16 $OUT/t22_fp32
 ls gpurun_out/profiles_staged

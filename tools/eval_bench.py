@@ -22,13 +22,14 @@ from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNe
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--two-kernel", action="store_true", help="encode_kernel + mlp_forward_kernel instead of the single fused forward kernel")
+ap.add_argument("--fused", action="store_true", help="the single fused forward kernel (NAF_CFG_FORWARD_FUSED, opt-in) instead of encode_kernel + mlp_forward_kernel")
+ap.add_argument("--two-kernel", action="store_true", help="(the default since round 3; kept for old command lines)")
 ap.add_argument("--two-gathers", action="store_true", help="NAF_CFG_ENCODE_TWO_GATHERS (two-kernel path only)")
 ap.add_argument("--store-features", action="store_true",
                 help="NAF_CFG_FUSED_STORE_FEATURES: the fused kernel also writes the [L, B, C] features (what the feature traffic alone costs it)")
 args = ap.parse_args()
 dev = torch.device("cuda")
-fused.forward_fused = not args.two_kernel
+fused.forward_fused = bool(args.fused) and not args.two_kernel
 if args.two_gathers:
     fused._default_flags |= 32
 if args.store_features:
@@ -59,7 +60,7 @@ with torch.no_grad():
     sv = geo.sVoxel / 2 - geo.dVoxel / 2
     t_grid = timed(lambda: fused.field_query_grid(net, [-float(v) for v in sv], [float(v) for v in sv], [256, 256, 256]))
     t_proj = timed(lambda: fused.fused_render(rays, net, 192, False))
-print(json.dumps({"precision": args.precision, "forward": "two kernels" if args.two_kernel or args.precision == "fp32" else "fused kernel",
+print(json.dumps({"precision": args.precision, "forward": "fused kernel" if fused.forward_fused and args.precision != "fp32" else "two kernels",
                   "two_gathers": args.two_gathers, "store_features": args.store_features,
                   "volume_query_256^3": {"points": voxels.numel() // 3, "ms": round(t_vol * 1e3, 3), "points_per_s": voxels.numel() / 3 / t_vol},
                   "volume_query_256^3_generated_grid": {"ms": round(t_grid * 1e3, 3), "points_per_s": voxels.numel() / 3 / t_grid},

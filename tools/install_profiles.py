@@ -15,6 +15,8 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "round3"
 
 
 def copy(src, dst):
+    if not os.path.exists(os.path.join(SRC, src)):       # the other part of tools/collect_profiles.sh produces it
+        return
     shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst))
     print("profiles/" + dst)
 
@@ -34,7 +36,7 @@ copy("bench_per_level_16384.json", f"{TAG}_bench_per_level_16384rays.json")
 for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"), ("bench_interleaved.json", "bench_levels_interleaved_encoder.json"), ("eval.jsonl", "eval_throughput.jsonl"),
                  ("train_py.json", "train_py_throughput.json"), ("shapes.jsonl", "other_shapes_step_times.jsonl"),
                  ("psnr_16384_bf16.json", "chest_psnr_vs_time_16384rays.json"), ("psnr_16384_fp32.json", "chest_psnr_vs_time_16384rays_fp32.json"),
-                 ("psnr_1024_bf16.json", "chest_psnr_vs_time_1024rays.json")):
+                 ("psnr_1024_bf16.json", "chest_psnr_vs_time_1024rays.json"), ("psnr_race_grid.jsonl", "psnr_race_grid.jsonl")):
     if os.path.exists(os.path.join(SRC, src)):
         copy(src, f"{TAG}_{dst}")
 
@@ -69,8 +71,9 @@ traffic = {
                 f"figures in profiles/{TAG}_pmc_bytes_per_dispatch_<R>rays.json, calibration in profiles/round3_cache_counters.md",
     "by_rays": by_rays,
 }
-json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
-print("profiles/pmc_traffic.json", {r: {k: round(v / 1e6, 1) for k, v in t["bf16"].items()} for r, t in by_rays.items()})
+if by_rays:                                            # (part B of tools/collect_profiles.sh has no counter passes)
+    json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+    print("profiles/pmc_traffic.json", {r: {k: round(v / 1e6, 1) for k, v in t["bf16"].items()} for r, t in by_rays.items()})
 
 
 # ---- T = 2^22: HBM bytes fetched by the fused forward's encoder ----------------------------------------------------------
@@ -140,5 +143,6 @@ for k in ("mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel",
         continue
     out.append(f"| {k} | {row['SQ_INSTS_MFMA']:.0f} | {row['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} | {row['SQ_BUSY_CU_CYCLES']:.0f} | "
                f"{100 * row['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * row['SQ_BUSY_CU_CYCLES']):.1f} % |")
-open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w").write("\n".join(out) + "\n")
-print("\n".join(out))
+if sq or mf:
+    open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))

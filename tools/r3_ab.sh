@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'rays':$rays,'flags':'$*','ms_per_step':round(d['ms_per_step'],4),'sustained_ms':d['sustained'] and d['sustained']['ms_per_step'],'kernels':d['kernels_ms_per_step']}))" >> $OUT/ab.jsonl
 }
-for f in "" "--bwd-one-wave" "--force-dp"; do run 1024 400 50 $f; done
-for r in 256 4096 65536; do run $r 50 5; done
-run 1024 300 30 --precision fp32
+for f in "" "--reduce-split 2" "--reduce-split 4" "" "--reduce-split 2" "--reduce-split 4"; do run 1024 400 50 $f; done
+for r in 256 4096 16384; do for f in "" "--reduce-split 2" "--reduce-split 4"; do run $r 50 5 $f; done; done
+run 1024 400 50 --force-dp
 echo ab done
