@@ -252,8 +252,9 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 0.6 s of back-to-back steps at the reference's batch size (a 20-step region is 6 ms: clocks and caches have not settled)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--rays", type=int, default=CHEST["yaml_rays"],
                     help="rays per GPU per step (default: chest_50.yaml's n_rays = 1024, the step that reconstructs fastest)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16", help="table storage / MLP operand type")
@@ -385,7 +386,7 @@ def main():
 
     # ---- per-kernel times: a second pass over the same kind of steps with a HIP-event pair around every kernel, on its launch
     # stream (naf_profile_*).  The events cost ~10 % at this step size, which is why this pass is not the timed region. ----------
-    prof_steps = max(args.steps, 50 if n <= 4096 else 10)
+    prof_steps = min(max(args.steps, 50 if n <= 4096 else 10), 200 if n <= 4096 else 20)
     engine.comm_timing(True)
     _abi.profile_enable(True)
     t0 = time.perf_counter()
