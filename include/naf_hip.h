@@ -90,7 +90,7 @@ int naf_hash_encode_backward(const void *grad, const float *inputs, const void *
  *   t_rand  f32 [n_rays, S]  jitter in [0,1) or NULL; with NULL and perturb != 0 the jitter is the
  *           counter-based generator naf_jitter(seed, ray, sample) documented in DESIGN.md
  *   z_vals  f32 [n_rays, S]  out
- *   pts     f32 [n_rays, S, 3] out, clamped to +-(bound - 1e-6)
+ *   pts     f32 [n_rays, S, 3] out, clamped to +-(bound - 1e-6); NULL: depths only
  */
 int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float *pts, uint32_t n_rays,
                     uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,

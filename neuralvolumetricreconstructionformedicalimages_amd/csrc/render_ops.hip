@@ -23,6 +23,7 @@ sample_rays_kernel(const float *__restrict__ rays, const float *__restrict__ t_r
         if (perturb) u = t_rand ? t_rand[i] : jitter(seed, ray_base + r, s);
         const float z = sample_z(near, far, s, S, perturb, u);
         z_vals[i] = z;
+        if (pts == nullptr) continue;                   // depths only (engine.sample_depths)
         const float lim = bound - 1e-6f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -92,7 +93,14 @@ fine_weight_max_kernel(const float *__restrict__ sigma, uint64_t total, uint32_t
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63u) == 0u && m > 0.0f) atomicMax(max_bits, __float_as_uint(m));
+    // one atomic per WORKGROUP, not per wave: same-address atomics retire one at a time (~12 ns each on MI355X)
+    __shared__ float wave_max[4];
+    if ((threadIdx.x & 63u) == 0u) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        if (m > 0.0f) atomicMax(max_bits, __float_as_uint(m));
+    }
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -232,7 +240,7 @@ using namespace naf;
 extern "C" int naf_sample_rays(const float *rays, const float *t_rand, float *z_vals, float *pts, uint32_t n_rays,
                                uint32_t n_samples, int perturb, float bound, uint64_t seed, uint32_t ray_index_base,
                                void *stream) {
-    if (n_rays != 0 && (!rays || !z_vals || !pts)) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: null pointer");
+    if (n_rays != 0 && (!rays || !z_vals)) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: null pointer");
     if (n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "sample_rays: n_samples must be >= 2");
     if (n_rays == 0) return NAF_OK;
     const uint64_t total = (uint64_t)n_rays * n_samples;

@@ -433,10 +433,25 @@ class NAFEngine:
         tail = sum(c0.elapsed_time(c1) for _, c0, _, c1 in steps) / len(steps)
         return {"allreduce_ms_per_step": in_flight, "tail_ms_per_step": tail}
 
-    def train_step(self, rays, target, weight, t_rand=None, ray_base=0):
-        """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
-        (device, no sync)."""
+    def sample_depths(self, rays, t_rand=None, ray_base=0):
+        """The sample depths z [n, S] the NEXT train_step / backward on these rays will use (explicit jitter, or the counter-based
+        generator keyed by this step's seed and the global ray index): what `raw_noise_std` needs to form its term."""
+        cfg = self._cfg(ray_base)
         n = rays.shape[0]
+        z = torch.empty(n, self.n_samples, device=self.device)
+        _abi.check(_abi.lib().naf_sample_rays(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(z), None, n, self.n_samples, int(self.perturb),
+                                              float(self.net.bound), cfg.seed, int(ray_base), _abi.stream_ptr()), "sample_rays")
+        return z
+
+    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None):
+        """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
+        (device, no sync).  `raw_noise_std` > 0 (render.py:196-199): the per-sample noise on sigma adds sum_s noise_s * dist_s to a
+        ray's line integral and nothing else (render.noise_line_integral), so the step runs on target - that term; `noise`: explicit
+        N(0, 1) draws [n, S] instead of torch.randn."""
+        n = rays.shape[0]
+        if float(raw_noise_std) > 0.0 and n > 0:
+            from .render import noise_line_integral
+            target = target - noise_line_integral(rays, self.sample_depths(rays, t_rand, ray_base), raw_noise_std, noise)
         if self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
             self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
         else:

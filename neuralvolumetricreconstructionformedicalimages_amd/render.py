@@ -34,6 +34,19 @@ def _sample(rays, n_samples, perturb, bound, t_rand):
     return z, pts
 
 
+def noise_line_integral(rays, z_vals, raw_noise_std, noise=None):
+    """What `raw_noise_std` adds to a ray's line integral.  render.py:196-201 computes acc = sum_s (sigma_s + noise_s) * dist_s with
+    noise ~ N(0, raw_noise_std^2) per sample: the noise enters ADDITIVELY (it is neither a network input nor part of the weights of
+    :203-211), so acc = acc_noise_free + sum_s noise_s * dist_s and the gradients of the loss see it only through d loss / d acc.
+    The fused kernels therefore stay noise-free and this term -- same distribution, sample for sample, as the reference's -- is
+    added to their output (or, for the training engine, subtracted from the target).  `noise`: explicit N(0,1) draws [n, S]."""
+    d = z_vals[..., 1:] - z_vals[..., :-1]
+    d = torch.cat([d, torch.full_like(d[..., :1], 1e-10)], -1) * torch.norm(rays[..., 3:6], dim=-1, keepdim=True)
+    if noise is None:
+        noise = torch.randn(z_vals.shape, device=z_vals.device)
+    return torch.sum(noise * float(raw_noise_std) * d, dim=-1)
+
+
 class _Integrate(Function):
     """acc[r] = sum_s sigma[r,s] * dist[r,s]   (render.py:192-201)."""
 
@@ -125,7 +138,8 @@ def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_
     if not perturb:
         t_rand = None
     fine = net_fine is not None and n_fine > 0
-    can_fuse = raw_noise_std == 0.0 and getattr(net, "fused_supported", lambda: False)()
+    can_fuse = getattr(net, "fused_supported", lambda: False)()     # raw_noise_std: additive term on acc (noise_line_integral)
+    noisy = float(raw_noise_std) > 0.0
     fused = (not fine) and can_fuse
     # coarse -> fine with both networks in the fused shape: three launches per pass instead of the reference's ATen soup --
     # coarse forward with per-sample sigma, naf_fine_depths (weights, cdf prefix sum, inverse sampling, sort), fine render
@@ -135,7 +149,7 @@ def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_
                   and n_samples <= 1024 and n_samples + n_fine <= 2048)
 
     z_vals = pts = None
-    if RETURN_PTS or not (fused or fused_fine):
+    if RETURN_PTS or noisy or not (fused or fused_fine):
         z_vals, pts = _sample(rays, n_samples, perturb, net.bound, t_rand)
     if fused_fine:
         acc0, sigma, _ = render_samples(rays, net, n_samples, perturb, t_rand=t_rand, want_depth=False)
@@ -143,6 +157,9 @@ def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_
         u = None if det else torch.rand(n_rays, n_fine, device=rays.device)        # same RNG stream position as render.py:230
         z_all, weights0 = fine_depths(rays, sigma, n_fine, perturb, t_rand=t_rand, u=u, det=det)
         acc = fused_render(rays, net_fine, n_samples + n_fine, False, z_vals=z_all)
+        if noisy:                                           # both passes draw their own noise (render.py:115,125)
+            acc0 = acc0 + noise_line_integral(rays, z_vals, raw_noise_std)
+            acc = acc + noise_line_integral(rays, z_all, raw_noise_std)
         ret = {"acc0": acc0, "weights0": weights0, "pts0": pts, "acc": acc}
         if RETURN_PTS:
             ret["pts"] = _points(rays, z_all, net.bound)
@@ -154,6 +171,8 @@ def render_chunk(rays, net, net_fine, n_samples, n_fine, perturb, netchunk, raw_
         return ret
     if fused:
         acc = fused_render(rays, net, n_samples, perturb, t_rand=t_rand)
+        if noisy:
+            acc = acc + noise_line_integral(rays, z_vals, raw_noise_std)
         weights = None
     else:
         raw = run_network(pts, net, netchunk)

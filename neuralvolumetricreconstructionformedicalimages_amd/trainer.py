@@ -131,12 +131,10 @@ class Trainer:
 
         self.engine = None
         want_fused = backend.get("engine", "fused") == "fused"
-        # the fused kernels have no noise input: a config that asks for raw_noise_std > 0 (render.py:186-190) runs through
-        # the module path, like any network shape the MFMA kernels are not specialised for
-        noise_free = float(cfg["render"].get("raw_noise_std", 0.0)) == 0.0
-        if want_fused and not noise_free:
-            print("[Trainer] render.raw_noise_std > 0: using the module back end (the fused engine is noise-free)")
-        if want_fused and noise_free and self.n_fine == 0 and self.net.fused_supported() and self.device.type == "cuda":
+        # raw_noise_std > 0 (render.py:196-199) is an additive term on the line integral (render.noise_line_integral): the fused engine
+        # handles it on the target side, the kernels stay noise-free
+        self.raw_noise_std = float(cfg["render"].get("raw_noise_std", 0.0))
+        if want_fused and self.n_fine == 0 and self.net.fused_supported() and self.device.type == "cuda":
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
                                     table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group,
@@ -146,7 +144,7 @@ class Trainer:
         elif self.group is not None:
             raise NotImplementedError("data-parallel training needs the fused engine (backend.engine: fused, n_fine: 0)")
         else:
-            if want_fused and noise_free and self.device.type == "cuda":      # say so instead of silently taking the slower path
+            if want_fused and self.device.type == "cuda":      # say so instead of silently taking the slower path
                 why = "n_fine > 0 (two networks)" if self.n_fine > 0 else \
                     "network / encoder shape outside the fused kernels (32 features, 4 layers of 32, skips [2], 1 output)"
                 print(f"[Trainer] {why}: using the module back end (autograd over the HIP operators + torch Linear layers)")
@@ -277,7 +275,8 @@ class Trainer:
                 projs = projs.float()
             weight = self.ray_weights(data, rays.shape[0])
             n = rays.shape[0]
-            loss = self.engine.train_step(rays, projs, weight, ray_base=(global_step * self.world + self.rank) * n)
+            loss = self.engine.train_step(rays, projs, weight, ray_base=(global_step * self.world + self.rank) * n,
+                                          raw_noise_std=self.raw_noise_std)
             if self.i_log > 0 and global_step % self.i_log == 0:
                 self.writer.add_scalar("train/loss", float(loss), global_step)
             return loss

@@ -115,6 +115,56 @@ def test_training_matches_oracle_psnr_at_jaw_size(table_dtype):
     assert abs(p - p_ref) < 0.1, (p, p_ref)
 
 
+def test_raw_noise_std_on_the_fused_engine_matches_the_oracle_with_the_same_noise():
+    """render.py:196-201 adds N(0, raw_noise_std^2) to sigma before the line integral: acc = sum_s (sigma_s + noise_s) * dist_s.  The
+    noise is additive on acc, so the fused engine keeps its kernels noise-free and shifts the target by sum_s noise_s * dist_s.
+    With the SAME noise values (one torch.randn of [n, S] after the same seed, as the oracle draws it) loss, projection and every
+    gradient equal the oracle's noisy step; the module-level render() takes the fused path too and returns the noisy acc."""
+    from neuralvolumetricreconstructionformedicalimages_amd import render as RR
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    from oracle import render_ref as R
+    from _naf_helpers import crossing_rays, rel_l2
+    net, ref = _pair(log2T=14, seed=7)
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    ref.encoder.embeddings.data.copy_(net.encoder.embeddings.data.cpu())
+    n, S, std = 96, 48, 0.3
+    rays = crossing_rays(n, seed=61)
+    t_rand = torch.rand(n, S, generator=torch.Generator().manual_seed(1))
+    target = torch.rand(n, generator=torch.Generator().manual_seed(2)) * 0.3
+    torch.manual_seed(77)
+    acc_ref = R.render(rays, ref, None, S, 0, True, 1 << 20, std, t_rand=t_rand)["acc"]          # draws randn([n, S]) once
+    loss_ref = ((acc_ref - target) ** 2).mean()
+    loss_ref.backward()
+    torch.manual_seed(77)
+    noise = torch.randn(n, S)                                                                     # the same values
+    engine = NAFEngine(net, S, perturb=True, lr=1e-3)
+    weight = torch.full((n,), 1.0 / n, device="cuda")
+    shifted = target.cuda() - RR.noise_line_integral(rays.cuda(), engine.sample_depths(rays.cuda(), t_rand.cuda()), std, noise.cuda())
+    acc = engine.backward(rays.cuda(), shifted, weight, t_rand=t_rand.cuda()).clone()
+    assert abs(float(engine.loss.item()) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+    assert rel_l2(engine.emb_g.cpu().numpy(), ref.encoder.embeddings.grad.numpy()) < 2e-4
+    g_mlp = torch.cat([torch.cat([l.weight.grad.reshape(-1), l.bias.grad.reshape(-1)]) for l in ref.layers])
+    assert rel_l2(engine.mlp_g.cpu().numpy(), g_mlp.numpy()) < 2e-4
+    # noise-free acc + the term == the oracle's noisy acc
+    noisy = acc + RR.noise_line_integral(rays.cuda(), engine.sample_depths(rays.cuda(), t_rand.cuda()), std, noise.cuda())
+    assert rel_l2(noisy.cpu().numpy(), acc_ref.detach().numpy()) < 1e-4
+    # train_step(raw_noise_std=...) is that shift; with the counter-based jitter it needs the depths of the step it is about to run
+    before = engine.emb.clone()
+    engine.emb_g.zero_(); engine.mlp_g.zero_()
+    engine.train_step(rays.cuda(), target.cuda(), weight, raw_noise_std=std)
+    assert float((engine.emb - before).abs().max()) > 0
+    # the reference-shaped render() keeps the fused kernels when raw_noise_std > 0: same statistics as the noise-free call
+    with torch.no_grad():
+        clean = RR.render(rays.cuda(), net, None, S, 0, True, 1 << 20, 0.0, t_rand=t_rand.cuda())["acc"]
+        torch.manual_seed(5)
+        dirty = RR.render(rays.cuda(), net, None, S, 0, True, 1 << 20, std, t_rand=t_rand.cuda())["acc"]
+    d = (dirty - clean).cpu()
+    z = engine.sample_depths(rays.cuda(), t_rand.cuda())
+    sigma_term = (std * torch.sqrt(((torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 1e-10, device="cuda")], -1)
+                                      * rays.cuda()[:, 3:6].norm(dim=-1, keepdim=True)) ** 2).sum(-1))).cpu()
+    assert float(d.abs().max()) > 0 and float((d / sigma_term).abs().max()) < 6.0        # N(0, std^2 sum dist^2) per ray
+
+
 def _cfg(tmp_path, data, engine="fused", epochs=2):
     return {
         "exp": {"expname": "t", "expdir": str(tmp_path), "datadir": data},

@@ -68,8 +68,7 @@ class BasicTrainer(Trainer):
         # The reference renders the projection n_rays at a time (train.py:235-238), each chunk with its own launches and a
         # host-side NaN check.  The fused path takes 65 536 rays per call instead: the same samples of the same rays
         # (jitter is drawn per ray), 4 calls instead of 256 for a 512 x 512 projection.
-        fused = (getattr(self.net, "fused_supported", lambda: False)() and self.net_fine is None
-                 and float(self.conf["render"].get("raw_noise_std", 0.0)) == 0.0)
+        fused = getattr(self.net, "fused_supported", lambda: False)() and self.net_fine is None
         step, inner = (max(self.n_rays, 1 << 16), None) if fused else (self.n_rays, 1024)
         for i in range(0, rays.shape[0], step):
             projs_pred.append(render(rays[i:i + step], self.net, self.net_fine, **self.conf["render"], chunk_size=inner)["acc"])
