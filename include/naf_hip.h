@@ -196,10 +196,13 @@ typedef struct naf_render_cfg {
 #define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
                                          (rounds 1-2) instead of one 16-byte window (same results; A/B timing only)      */
 #define NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD 128u /* diagnostics: the MLP backward splits rays into tile ranges only up to one wave per SIMD (rounds 1-2) instead of three */
-#define NAF_CFG_LEVELS_XCD_PINNED 256u /* the encoder gives XCD k the levels k, k + 8, ... (see encode_kernel) whatever the batch size;
-                                          without the flag it does so below 120 000 points per call, where that order is faster  */
+#define NAF_CFG_ENCODE_LEVEL_MAJOR 256u /* diagnostics: the encoder never splits the XCDs into groups (see NAF_CFG_ENCODE_GROUPS_*)       */
 #define NAF_CFG_ENCODE_WINDOW4 64u     /* diagnostics: four points per thread in the window encoder instead of two                 */
 #define NAF_CFG_FUSED_STORE_FEATURES 16u /* diagnostics: the fused kernel also stores the features it computed              */
+#define NAF_CFG_ENCODE_GROUPS_2 512u     /* the encoder splits the eight XCDs into 2 groups that take alternate levels, so that a level's
+                                            slice of the table is pulled through four L2s instead of eight (encode_kernel); without a
+                                            flag the batch size decides: 4 groups below 160 000 points per call, 2 below 500 000    */
+#define NAF_CFG_ENCODE_GROUPS_4 1024u    /* ... into 4 groups (levels mod 4); both flags: 8 groups, one level per XCD at a time       */
 #define NAF_CFG_TEST_TINY_BLOCKS 4096u   /* tests: the record blocks of pass 1 hold a quarter of a tile's records, so that most
                                             records take the overflow route (counted global atomics) and the reducer's Adam tail has
                                             spilled contributions to fold in                                                        */

@@ -25,7 +25,9 @@ CFG_FUSED_STORE_FEATURES = 16
 CFG_ENCODE_TWO_GATHERS = 32
 CFG_ENCODE_WINDOW4 = 64
 CFG_BACKWARD_ONE_WAVE_PER_SIMD = 128
-CFG_LEVELS_XCD_PINNED = 256
+CFG_ENCODE_LEVEL_MAJOR = 256
+CFG_ENCODE_GROUPS_2 = 512
+CFG_ENCODE_GROUPS_4 = 1024
 CFG_TEST_TINY_BLOCKS = 4096
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 

@@ -882,7 +882,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_LEVELS_XCD_PINNED | NAF_CFG_TEST_TINY_BLOCKS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -897,19 +897,33 @@ __host__ __device__ constexpr uint32_t encode_points_per_thread(uint32_t C) { re
 template <typename TT, typename FT, uint32_t C, typename Src, uint32_t kWindow>        // kWindow: 0 = two gathers per pair, else points per thread
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, uint32_t order, uint32_t n_levels, uint32_t total_levels) {
-    // order 0 -- level-major (default): blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and that
-    //   level's slice of the table stays in the L2s.
+              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, uint32_t order, uint32_t n_levels, uint32_t total_levels,
+              uint32_t tiles) {
+    // order 0 -- level-major (large batches): blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and
+    //   that level's slice of the table stays in the L2s (98.6 % hits).
     // order 1 -- NAF_CFG_LEVELS_INTERLEAVED (diagnostic): the level in x, every XCD walks levels k and k + 8 at once.
-    // order 2 -- XCD-pinned (small batches): workgroups go to the eight XCDs round-robin, so workgroup b belongs to XCD b % 8, which
-    //   takes the levels b % 8, b % 8 + 8, ... one after the other.  Each L2 then fills with its own levels only: a step pulls the
-    //   table through the L2s once (28.5 MB at T = 2^19, bf16) instead of once per XCD (228 MB) -- what a 1 024-ray step, whose
-    //   196 608 points touch every line of every level anyway, spends much of its encode time on.
     const uint32_t table_rows = (uint32_t)offsets[total_levels];
-    for (uint32_t level = level_base + (order == 1u ? blockIdx.x : order == 2u ? blockIdx.x % 8u : blockIdx.y);
-         level < level_base + n_levels; level += (order == 2u ? 8u : n_levels)) {
-    const uint32_t block_x = order == 1u ? blockIdx.y : order == 2u ? blockIdx.x / 8u : blockIdx.x;
-    const uint32_t grid_x = order == 1u ? gridDim.y : order == 2u ? gridDim.x / 8u : gridDim.x;
+    // order 4 + log2 G -- XCD GROUPS (small and medium batches): the eight XCDs form G groups of 8 / G; group g takes the levels
+    //   g, g + G, ... one after the other and spreads each level's `tiles` workgroup-sized pieces over its XCDs, dispatched in
+    //   order.  A level is then pulled through 8 / G L2s instead of all eight -- at the reference's batch size the table fills are
+    //   most of what the encoder fetches (0.24 GB per launch by PMC: 8 x 28.5 MB) -- while even / odd levels (G = 2) or levels mod 4
+    //   (G = 4) balance within 0.5 % / 4 % (profiles/round3_bench_per_level_16384rays.json); G = 8 (one level per XCD at a time)
+    //   is 14 % off balance however the levels are paired.  Workgroup b sits on XCD b mod 8 (round-robin dispatch: a property
+    //   used for speed only, any placement gives the same bits).
+    uint32_t g_level = 0u, g_block = 0u;
+    bool g_idle = false;
+    if (order >= 4u) {
+        const uint32_t log2g = order - 4u, G = 1u << log2g, per = 8u >> log2g, xcd = blockIdx.x & 7u;
+        const uint32_t u = (blockIdx.x >> 3) * per + (xcd % per);           // piece index inside the group
+        g_level = xcd / per + G * (u / tiles);
+        g_block = u % tiles;
+        g_idle = g_level >= n_levels;                                       // padding workgroups of a grid rounded up to 8
+    }
+    if (g_idle) return;
+    {
+    const uint32_t level = level_base + (order >= 4u ? g_level : order == 1u ? blockIdx.x : blockIdx.y);
+    const uint32_t block_x = order >= 4u ? g_block : order == 1u ? blockIdx.y : blockIdx.x;
+    const uint32_t grid_x = order >= 4u ? tiles : order == 1u ? gridDim.y : gridDim.x;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
@@ -1003,22 +1017,26 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
         for (uint32_t l = 0; l < cfg->L; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L);
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L, 0u);
         }
         return check_launch("encode_kernel");
     }
     const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
     const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
-    // small batches pull every level through all eight L2s for a handful of points each: below ~600 rays x 192 samples the pinned
-    // order wins (256 rays: 0.036 -> 0.024 ms, 512: 0.047 -> 0.040), from 1 024 rays on level-major does (0.067 vs 0.070)
-    constexpr uint32_t kPinnedMaxPoints = 120000u;
-    const bool pinned = !interleaved && cfg->L >= 8u && ((cfg->flags & NAF_CFG_LEVELS_XCD_PINNED) != 0u || B <= kPinnedMaxPoints);
-    const uint32_t order = interleaved ? 1u : pinned ? 2u : 0u;
-    // pinned: 8 XCDs x up to 160 workgroups each = what is resident at once (32 CUs x 5 waves per SIMD at 94 VGPRs; more would queue
-    // behind the first round on some XCDs and unbalance them)
-    const dim3 grid = interleaved ? dim3(cfg->L, gx) : pinned ? dim3(8u * std::min(gx, 160u)) : dim3(gx, cfg->L);
+    // XCD groups (order 4 + log2 G; see encode_kernel): a level is pulled through 8 / G L2s instead of eight.  Measured on the chest
+    // step (encode_kernel, ms; level-major / G = 2 / 4 / 8): 256 rays 0.036 / 0.029 / 0.023 / 0.023, 512: 0.047 / 0.038 / 0.034 / 0.037,
+    // 1 024: 0.068 / 0.061 / 0.061 / 0.067, 2 048: 0.111 / 0.108 / 0.110 / 0.121, 4 096: 0.202 / 0.202 / 0.207 / 0.230, 16 384:
+    // 0.735 / 0.753 / 0.791 / 0.884 -- four groups below 160 000 points, two below 500 000, level-major above.
+    // NAF_CFG_ENCODE_GROUPS_2 / _4 / both (= 8) force G, NAF_CFG_ENCODE_LEVEL_MAJOR forces none.
+    uint32_t log2g = B < 160000u ? 2u : B < 500000u ? 1u : 0u;
+    if ((cfg->flags & (NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) != 0u)
+        log2g = ((cfg->flags & NAF_CFG_ENCODE_GROUPS_2) != 0u ? 1u : 0u) + ((cfg->flags & NAF_CFG_ENCODE_GROUPS_4) != 0u ? 2u : 0u);
+    if ((cfg->flags & NAF_CFG_ENCODE_LEVEL_MAJOR) != 0u) log2g = 0u;
+    const bool grouped = !interleaved && log2g != 0u && cfg->L % (1u << log2g) == 0u && cfg->L >= 8u;
+    const uint32_t order = interleaved ? 1u : grouped ? 4u + log2g : 0u;
+    const dim3 grid = interleaved ? dim3(cfg->L, gx) : grouped ? dim3((cfg->L * gx + 7u) / 8u * 8u) : dim3(gx, cfg->L);
     { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, order, cfg->L, cfg->L); }
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, order, cfg->L, cfg->L, gx); }
     return check_launch("encode_kernel");
 }
 

@@ -133,6 +133,22 @@ def test_window_gathers_equal_two_gathers(table, C, log2T):
     assert torch.equal(out[0], out[_abi.CFG_ENCODE_TWO_GATHERS])
 
 
+def test_encoder_xcd_group_orders_give_the_same_bits():
+    """The encoder's launch orders -- level-major and 2 / 4 / 8 XCD groups taking alternate levels -- only change
+    which workgroup computes which (level, tile): identical projections for ragged and for multi-tile batches."""
+    _abi, fused = _mods()
+    net, _ = naf_pair(seed=9, log2T=15, oracle=False)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.to(torch.bfloat16)
+    for n, S in ((5, 37), (700, 192), (3000, 64)):
+        rays = crossing_rays(n, seed=n).cuda()
+        t_rand = torch.rand(n, S, device="cuda")
+        base = _render(net, rays, S, 0, t_rand)
+        for flags in (_abi.CFG_ENCODE_GROUPS_2, _abi.CFG_ENCODE_GROUPS_4, _abi.CFG_ENCODE_GROUPS_2 | _abi.CFG_ENCODE_GROUPS_4,
+                      _abi.CFG_ENCODE_LEVEL_MAJOR):
+            assert torch.equal(_render(net, rays, S, flags, t_rand), base), (n, S, flags)
+    assert float(base.abs().max()) > 0
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
 def test_volume_query_in_ranges_is_bit_identical(prec):
     _abi, fused = _mods()
