@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--two-gathers", action="store_true",
                     help="diagnostics: the encoder fetches x-neighbour corners with two gathers instead of one 16-byte window "
                          "(NAF_CFG_ENCODE_TWO_GATHERS)")
-    ap.add_argument("--window4", action="store_true", help="diagnostics: NAF_CFG_ENCODE_WINDOW4")
+    ap.add_argument("--windows", action="store_true", help="diagnostics: NAF_CFG_ENCODE_WINDOWS (16-byte window gathers at every batch size)")
     ap.add_argument("--bwd-one-wave", action="store_true", help="diagnostics: NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD")
     ap.add_argument("--encode-groups", type=int, choices=[0, 1, 2, 4, 8], default=0, help="XCD groups of the encoder (NAF_CFG_ENCODE_GROUPS_*; 1: level-major, 0: by batch size)")
     ap.add_argument("--separate-adam", action="store_true",
@@ -337,7 +337,7 @@ def main():
                                  n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
                                  scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
                                  cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
-                                           | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOW4 if args.window4 else 0) | (_abi.CFG_BACKWARD_ONE_WAVE_PER_SIMD if args.bwd_one_wave else 0) | {0: 0, 1: _abi.CFG_ENCODE_LEVEL_MAJOR, 2: _abi.CFG_ENCODE_GROUPS_2, 4: _abi.CFG_ENCODE_GROUPS_4, 8: _abi.CFG_ENCODE_GROUPS_2 | _abi.CFG_ENCODE_GROUPS_4}[args.encode_groups],
+                                           | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOWS if args.windows else 0) | (_abi.CFG_BACKWARD_ONE_WAVE_PER_SIMD if args.bwd_one_wave else 0) | {0: 0, 1: _abi.CFG_ENCODE_LEVEL_MAJOR, 2: _abi.CFG_ENCODE_GROUPS_2, 4: _abi.CFG_ENCODE_GROUPS_4, 8: _abi.CFG_ENCODE_GROUPS_2 | _abi.CFG_ENCODE_GROUPS_4}[args.encode_groups],
                                  bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode,
                                  rays_per_step_hint=args.rays)
 

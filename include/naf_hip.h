@@ -194,10 +194,11 @@ typedef struct naf_render_cfg {
                                          channels, bf16 MLP operands); the [L, B, C] features then never reach HBM and the calls
                                          need no workspace (naf_forward_workspace_bytes).  Bit-identical to the two-kernel path. */
 #define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
-                                         (rounds 1-2) instead of one 16-byte window (same results; A/B timing only)      */
+                                         at every batch size instead of one 16-byte window (same results; A/B timing only) */
 #define NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD 128u /* diagnostics: the MLP backward splits rays into tile ranges only up to one wave per SIMD (rounds 1-2) instead of three */
 #define NAF_CFG_ENCODE_LEVEL_MAJOR 256u /* diagnostics: the encoder never splits the XCDs into groups (see NAF_CFG_ENCODE_GROUPS_*)       */
-#define NAF_CFG_ENCODE_WINDOW4 64u     /* diagnostics: four points per thread in the window encoder instead of two                 */
+#define NAF_CFG_ENCODE_WINDOWS 64u     /* diagnostics: the 16-byte window form at every batch size (default: below 600 000 points per
+                                          call and for fp32 tables; two gathers with four points per lane in flight above)        */
 #define NAF_CFG_FUSED_STORE_FEATURES 16u /* diagnostics: the fused kernel also stores the features it computed              */
 #define NAF_CFG_ENCODE_GROUPS_2 512u     /* the encoder splits the eight XCDs into 2 groups that take alternate levels, so that a level's
                                             slice of the table is pulled through four L2s instead of eight (encode_kernel); without a

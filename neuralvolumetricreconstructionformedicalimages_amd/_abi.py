@@ -23,7 +23,7 @@ CFG_LEVELS_INTERLEAVED = 4
 CFG_FORWARD_FUSED = 8
 CFG_FUSED_STORE_FEATURES = 16
 CFG_ENCODE_TWO_GATHERS = 32
-CFG_ENCODE_WINDOW4 = 64
+CFG_ENCODE_WINDOWS = 64
 CFG_BACKWARD_ONE_WAVE_PER_SIMD = 128
 CFG_ENCODE_LEVEL_MAJOR = 256
 CFG_ENCODE_GROUPS_2 = 512

@@ -220,7 +220,6 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
                      float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items, uint32_t B, int act,
                      OutMap omap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Mlp16Shared::build<4>(smem, mlp);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
     Act16 a;
@@ -230,6 +229,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
         float *zbuf = reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u)) + (threadIdx.x >> 6) * kMaxSamplesLds;
         Feat16Raw ahead;                                     // features of the next tile, in flight during this one
         if (wave < n_items) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
+        Mlp16Shared::build<4>(smem, mlp);                    // after the first feature request: the two round trips overlap
         for (uint32_t r = wave; r < n_items; r += n_waves) {
             const float *ray = src.rays + (size_t)r * 8;
             const float near = ray[6], far = ray[7];
@@ -259,6 +259,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             if (lane == 0) out[r] = part;
         }
     } else {
+        Mlp16Shared::build<4>(smem, mlp);
         const uint32_t tiles = (n_items + 15u) / 16u;
         for (uint32_t k = wave; k < tiles; k += n_waves) {
             const uint32_t p0 = 16u * k + c;
@@ -534,7 +535,6 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
                       uint32_t n_rays, uint32_t B, int act, uint32_t parts, uint32_t *__restrict__ clear_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (clear_words != nullptr && blockIdx.x == 0u && threadIdx.x < kClearWords) clear_words[threadIdx.x] = 0u;      // see StepExtras
-    Mlp16Shared::build<8>(smem, mlp);
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
     // wave-uniform values are made scalar explicitly: the ray record, its depths range and d acc then live in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -571,6 +571,9 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     auto first_tile = [&](uint32_t part) { return part * tiles / parts; };
     Feat16Raw ahead;
     if (wave < n_items) load_feat16(feat, B, ray_of(wave) * S + min(16u * first_tile(wave - ray_of(wave) * parts) + c, S - 1u), g, ahead);
+    // the weight fragments are built AFTER the first tile's features have been requested: the two round trips overlap (the build
+    // ends with the workgroup barrier that makes the fragments visible)
+    Mlp16Shared::build<8>(smem, mlp);
     for (uint32_t item = wave; item < n_items; item += n_waves) {
         const uint32_t r = ray_of(item), part = item - r * parts, k_begin = first_tile(part), k_end = first_tile(part + 1u);
         const float *ray = src.rays + (size_t)r * 8;
@@ -882,7 +885,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOW4 | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1007,11 +1010,17 @@ template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
     using FT = typename P::feat_t;
     constexpr bool kCanWindow = PairWindow<TT, C>::kUsable;
-    const bool window = kCanWindow && (cfg->flags & NAF_CFG_ENCODE_TWO_GATHERS) == 0u;
-    const bool window4 = window && (cfg->flags & NAF_CFG_ENCODE_WINDOW4) != 0u;
+    // x-neighbour corners through ONE 16-byte window per pair (fewer L1 accesses: what small batches are bound by) or through two
+    // gathers with four points per lane in flight (more misses outstanding: what large batches are bound by).  Measured
+    // (encode_kernel, window / two gathers, ms): 1 024 rays 0.067 / 0.088, 2 048: 0.115 / 0.117, 4 096: 0.216 / 0.211, 16 384:
+    // 0.777 / 0.753, 65 536: 3.00 / 2.89; T = 2^22 fp16 (foot) 6.20 / 5.85; fp32 tables (a window covers only the mask-1 pairs, but
+    // the L1 is the tighter resource there) 0.908 / 1.008 at 16 384 rays.  NAF_CFG_ENCODE_TWO_GATHERS / _WINDOWS force one form.
+    bool window = kCanWindow && (B < 600000u || sizeof(typename TT::store_t) == 4u);
+    if ((cfg->flags & NAF_CFG_ENCODE_WINDOWS) != 0u) window = kCanWindow;
+    if ((cfg->flags & NAF_CFG_ENCODE_TWO_GATHERS) != 0u) window = false;
     auto kern = encode_kernel<TT, FT, C, Src, 0u>;
-    if constexpr (kCanWindow) { if (window) kern = window4 ? encode_kernel<TT, FT, C, Src, 4u> : encode_kernel<TT, FT, C, Src, 2u>; }
-    const uint32_t kPts = window4 ? 4u : window ? 2u : encode_points_per_thread(C);
+    if constexpr (kCanWindow) { if (window) kern = encode_kernel<TT, FT, C, Src, 2u>; }
+    const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
         for (uint32_t l = 0; l < cfg->L; ++l) {
