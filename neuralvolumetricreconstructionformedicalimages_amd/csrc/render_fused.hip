@@ -6,12 +6,14 @@
 // its sample position from the 32-byte ray record and the jitter (explicit t_rand or the counter-based generator).
 //
 // Kernels of one training step (B = n_rays * S points, feature tensors are [L, B, C]):
-//   1 encode_kernel                  gathers  -> feat                 level-major, four points per lane
+//   1 encode_kernel                  gathers  -> feat                 level-major, or XCD groups taking alternate levels below 500 k
+//                                                                      points; 16-byte window gathers below 600 k points, two gathers above
 //   2 mlp_forward_kernel             feat -> sigma -> acc[r]          one wave per ray, wave-reduced line integral
-//   3 mlp_backward_kernel            feat, (acc, target, weight | d acc) -> dfeat, per-workgroup dW slabs + loss share
-//   4 scatter_bin / scatter_reduce / scatter_apply (scatter_binned.h)   dfeat -> grad table, no global atomics;
-//     hash_backward_kernel<SrcRays> (hash_kernels.h, fp32 atomics like the reference) below 2^13 points per call
-//   5 mlp_grad_reduce_kernel         slabs -> grad_mlp (+=) or the MLP's Adam update, loss (+=)
+//   3 mlp_backward_kernel            feat, (acc, target, weight | d acc) -> dfeat, per-workgroup slabs: dW, loss share, max |dfeat|
+//   4 scatter_bin / scatter_reduce (scatter_binned.h)   dfeat -> grad table (or, with the Adam tail, straight into the table's update),
+//     no global atomics; spare workgroups of the first scatter_bin launch reduce the slabs of 3 (mlp_slabs.h): MLP gradient or the
+//     MLP's Adam update, loss, gradient maximum.  hash_backward_kernel<SrcRays> (hash_kernels.h, fp32 atomics like the reference)
+//     below 2^13 points per call, with mlp_grad_reduce_kernel as a launch of its own (also on data-parallel steps).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
