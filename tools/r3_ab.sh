@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'rays':$rays,'flags':'$*','ms_per_step':round(d['ms_per_step'],4),'sustained_ms':d['sustained'] and d['sustained']['ms_per_step'],'kernels':d['kernels_ms_per_step']}))" >> $OUT/ab.jsonl
 }
-for r in 256 512 1024 2048 4096 16384; do for g in 0 2 4 8; do run $r 300 30 --encode-groups $g; done; done
-run 65536 20 3 --encode-groups 0
-run 65536 20 3 --encode-groups 2
+for r in 256 1024 1024 4096 65536; do run $r 300 30; done
+run 1024 300 30 --precision fp32
+run 1024 300 30 --separate-adam
 echo ab done
