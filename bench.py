@@ -237,11 +237,19 @@ def psnr_race(scan, n_rays, lr, precision="bf16", thresholds=(30.0, 35.0, 38.0),
             reached[f"{pending.pop(0):g}dB"] = {"train_s": round(t_train, 4), "steps": steps, "rays": steps * n_rays}
     for th in pending:
         reached[f"{th:g}dB"] = None                                     # not reached inside max_train_s
+    # The curve is not monotone (at the reference's learning rate it oscillates by +-1.5 dB between 32 and 35 dB for seconds), so the
+    # FIRST crossing of a threshold can fall on a lucky peak: `held_from` is the training time from which the PSNR stayed at or above
+    # the threshold until the end of the race (for the highest threshold reached that is its first crossing: the race stops there).
+    held = {}
+    for th in sorted(thresholds):
+        below = [i for i, c in enumerate(curve) if c["psnr_db"] < th]
+        first_ok = (below[-1] + 1) if below else 0
+        held[f"{th:g}dB"] = None if first_ok >= len(curve) else {"train_s": curve[first_ok]["train_s"], "steps": curve[first_ok]["steps"]}
     keep = curve[::max(1, len(curve) // 24)]
     if keep[-1] is not curve[-1]:
         keep.append(curve[-1])
     return {"rays_per_step": n_rays, "lr": lr, "precision": precision, "loss": loss_name, "burst_steps": burst,
-            "time_to_psnr": reached, "final": curve[-1], "train_seconds": round(t_train, 4), "steps": steps,
+            "time_to_psnr": reached, "held_from": held, "final": curve[-1], "train_seconds": round(t_train, 4), "steps": steps,
             "sustained_rays_per_s": steps * n_rays / t_train, "ms_per_step": round(t_train / steps * 1e3, 4), "curve": keep}
 
 

@@ -295,10 +295,7 @@ int naf_field_forward_grid(const double *start, const double *stop, const uint32
 /* ------------------------------------------------------------------------------------------------
  * T4  Adam (torch.optim.Adam semantics, trainer.py:54: lr, betas=(0.9,0.999), eps=1e-8, no weight decay,
  * amsgrad off).  `step` is the 1-based step count.  If param_lp != NULL a low-precision copy of the
- * updated parameters (naf_dtype lp_dtype) is written too (16-bit tables keep an fp32 master); the update then uses the hardware
- * reciprocal and square root (1 ulp each) in place of torch's two IEEE divisions and corrected root -- the shadow's 8 / 11 mantissa
- * bits swallow the difference, and the reducer's Adam tail (naf_render_train_adam) follows the same rule, so both routes agree
- * bit for bit.  Without a shadow (fp32 parity mode, the MLP) torch's operation sequence is kept to the rounding.
+ * updated parameters (naf_dtype lp_dtype) is written too (16-bit tables keep an fp32 master).
  * If zero_grad != 0 the gradient buffer is cleared in the same pass.
  */
 /* One training step of the TABLE in one call (single-GPU steps): naf_render_train whose gradient reducer applies the Adam

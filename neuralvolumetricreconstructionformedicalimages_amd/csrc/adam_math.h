@@ -11,27 +11,19 @@ namespace naf {
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale;
-    float step_size, inv_bias2_sqrt;       // lr / bias1 and 1 / bias2_sqrt, rounded once on the host (fast form only)
 };
 
-// kFast = false: torch's operation sequence with correctly rounded sqrt and divisions (fp32 parity mode, the MLP, any table without a
-// 16-bit shadow).  kFast = true: the same update with one hardware reciprocal and the hardware square root (1 ulp each) in place
-// of the two IEEE divisions and the corrected root -- 24 fewer vector instructions per element, which matters where the update is
-// issue-bound (the tail of the gradient reducer at small batches: profiles/round3_wave_state.md).  Used exactly where the table the
-// kernels READ is a 16-bit shadow of the master: its 8 or 11 mantissa bits swallow a 1-ulp difference in the fp32 master many times
-// over.  Both routes to a table update (reducer tail, adam_kernel) pick the form by the same rule, so they still give the same bits.
-template <bool kFast = false>
+// torch's operation sequence with correctly rounded sqrt and divisions.  (A form with one hardware reciprocal and the hardware square
+// root -- 1 ulp each, 24 fewer vector instructions per element -- was measured for tables that keep a 16-bit shadow: the reducer's
+// tail is issue-bound at small batches and gained 7 us of 112 at 1 024 rays.  It is not used: the chest run at the reference's
+// learning rate oscillates around 35 dB between 3 and 7 s of training, and the ulp-level change moved the first crossing of that
+// threshold from 3.4 to 7.2 s -- a reminder that the optimiser is the one place where this code follows torch to the rounding.)
 __device__ __forceinline__ float adam_one(float &p, float &m, float &v, float g, const AdamArgs &a) {
     g *= a.grad_scale;
     m = m + (g - m) * (1.0f - a.beta1);                    // torch: exp_avg.lerp_(grad, 1-beta1)
     v = v * a.beta2 + (1.0f - a.beta2) * g * g;            // torch: exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-    if constexpr (kFast) {
-        const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_bias2_sqrt + a.eps;      // (a denormal v is far below eps^2 either way)
-        p = p - a.step_size * (m * __builtin_amdgcn_rcpf(denom));
-    } else {
-        const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;   // torch: (sqrt(v)/sqrt(bias2)).add_(eps)
-        p = p - (a.lr / a.bias1) * (m / denom);                // torch: param.addcdiv_(m, denom, -lr/bias1)
-    }
+    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;   // torch: (sqrt(v)/sqrt(bias2)).add_(eps)
+    p = p - (a.lr / a.bias1) * (m / denom);                // torch: param.addcdiv_(m, denom, -lr/bias1)
     return p;
 }
 

@@ -1170,8 +1170,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     if constexpr (kHasBig) {
         if (big) bin = many ? scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvMany> : scatter_bin_kernel<FT, C, SrcRays, Rec, 2u * NT, PTS, kLvFew>;
     }
-    // the Adam tail in its exact form (fp32 table: no shadow) or its fast form (the kernels read a 16-bit shadow): adam_math.h
-    auto red = adam == nullptr ? scatter_reduce_kernel<C, Rec, 0> : adam->lp == nullptr ? scatter_reduce_kernel<C, Rec, 1> : scatter_reduce_kernel<C, Rec, 2>;
+    auto red = adam != nullptr ? scatter_reduce_kernel<C, Rec, true> : scatter_reduce_kernel<C, Rec, false>;
     const AdamTail tail = adam != nullptr ? *adam : AdamTail{};
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * C * 8u;

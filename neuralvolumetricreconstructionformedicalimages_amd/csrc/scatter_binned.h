@@ -400,12 +400,11 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 // kAdam (naf_render_train_adam, single-GPU steps): the workgroup is the sole owner of its rows and has their finished sums in
 // LDS, so instead of writing the gradient out for a separate Adam pass to read back and clear it applies the update itself --
 // the 57 MB gradient table is then neither written, re-read nor zeroed (only rows that pass 1 reached with atomics are).
-template <uint32_t C, typename Rec, int kAdamForm = 0>       // 0: gradient out; 1: Adam tail, exact form; 2: fast form (adam_math.h)
+template <uint32_t C, typename Rec, bool kAdam = false>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base,
                       uint32_t ly_begin, BinPlan plan, AdamTail adam) {
-    constexpr bool kAdam = kAdamForm != 0, kFastAdam = kAdamForm == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift(gbits);
@@ -600,7 +599,7 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 const float extra = gg[e];
                 if (extra != 0.0f) { g = extra + g; gg[e] = 0.0f; }          // the order of the separate route: table += sum
             }
-            adam_one<kFastAdam>(p, m, v, g, adam.a);
+            adam_one(p, m, v, g, adam.a);
             pp[e] = p; pm[e] = m; pv[e] = v;
             if (adam.lp != nullptr) {
                 const size_t el = (size_t)off * C + e;
@@ -642,7 +641,7 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 }
                 float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) adam_one<kFastAdam>(p[j], m[j], v[j], g[j], adam.a);
+                for (uint32_t j = 0; j < 4; ++j) adam_one(p[j], m[j], v[j], g[j], adam.a);
                 *reinterpret_cast<Quad *>(pp + e) = Quad{p[0], p[1], p[2], p[3]};
                 *reinterpret_cast<Quad *>(pm + e) = Quad{m[0], m[1], m[2], m[3]};
                 *reinterpret_cast<Quad *>(pv + e) = Quad{v[0], v[1], v[2], v[3]};
