@@ -157,7 +157,7 @@ struct OutMap {
 // ---- 2: MLP forward + line integral ----------------------------------------------------------------------
 // kRays: one wave per ray, acc[r] = sum_s sigma*dist.   !kRays: plain point list, out[p] = sigma(p).
 template <typename P, uint32_t C, bool kRays>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 2)        // 3 waves per SIMD cost the fp32 kernel 91 spilled registers per lane
 mlp_forward_kernel(const typename P::feat_t::store_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src,
                    float *__restrict__ out, float *__restrict__ sigma_out, float *__restrict__ depth_out, uint32_t n_items,
                    uint32_t B, int act, OutMap omap) {

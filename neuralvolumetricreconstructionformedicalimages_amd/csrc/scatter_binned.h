@@ -328,17 +328,23 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         lds_barrier();
 
         // ---- C: placement -------------------------------------------------------------------------------------------------
-        auto place = [&](uint32_t b, const uint32_t (&words)[K], uint32_t row_a, uint32_t row_b, const Rec &r) {
+        auto place = [&](uint32_t b, const uint32_t (&words)[K], uint32_t row_a, uint32_t row_b, const Rec &r) __attribute__((always_inline)) {
             const uint32_t pos = atomicAdd(&cursor[b], 1u);
             if (pos < SLOTS) {
                 uint32_t *dst = staging + (size_t)pos * K;
 #pragma unroll
                 for (uint32_t i = 0; i < K; ++i) dst[i] = words[i];
             } else {                                                     // the tile's block is full (see the header): straight to the table
+                // (values are read out BEFORE the row test: with fp32 records the compiler otherwise selects the record WORD by the
+                // test -- a dynamically indexed private array, which sent all of `rec` to scratch memory: 176 bytes per lane in the
+                // fp32-mode kernel for the sake of a branch that is almost never taken)
+                float va[C], vb[C];
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ++ch) { va[ch] = r.value(0, ch); vb[ch] = r.value(1, ch); }
 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ++ch) {
-                    atomicAdd(gg + (size_t)row_a * C + ch, r.value(0, ch));
-                    if (row_b != row_a) atomicAdd(gg + (size_t)row_b * C + ch, r.value(1, ch));
+                    atomicAdd(gg + (size_t)row_a * C + ch, va[ch]);
+                    if (row_b != row_a) atomicAdd(gg + (size_t)row_b * C + ch, vb[ch]);
                 }
                 ++n_overflow;
                 ++n_overflow_level;
@@ -355,7 +361,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 if (lone[q][k] == kNoRow) {
                     place(bkt[q][k], r.w, row_a, row_of(bkt[q][k], la ^ (r.w[0] >> 16), plan.log2_nb), r);
                 } else {                                                  // two single records: first corner, second corner
-                    Rec a = r, b2;
+                    Rec a, b2;
                     float va[C], vb[C], zero[C];
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) { va[ch] = r.value(0, ch); vb[ch] = r.value(1, ch); zero[ch] = 0.0f; }

@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'rays':$rays,'flags':'$*','ms_per_step':round(d['ms_per_step'],4),'sustained_ms':d['sustained'] and d['sustained']['ms_per_step'],'kernels':d['kernels_ms_per_step']}))" >> $OUT/ab.jsonl
 }
-for r in 256 1024 1024 4096 65536; do run $r 300 30; done
 run 1024 300 30 --precision fp32
-run 1024 300 30 --separate-adam
+run 16384 30 3 --precision fp32
+run 65536 10 3 --precision fp32
 echo ab done
