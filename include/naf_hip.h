@@ -296,7 +296,8 @@ int naf_field_forward_grid(const double *start, const double *stop, const uint32
  * T4  Adam (torch.optim.Adam semantics, trainer.py:54: lr, betas=(0.9,0.999), eps=1e-8, no weight decay,
  * amsgrad off).  `step` is the 1-based step count.  If param_lp != NULL a low-precision copy of the
  * updated parameters (naf_dtype lp_dtype) is written too (16-bit tables keep an fp32 master).
- * If zero_grad != 0 the gradient buffer is cleared in the same pass.
+ * If zero_grad != 0 the gradient buffer is cleared in the same pass.  param / exp_avg / exp_avg_sq / grad must be 16-byte
+ * aligned when n >= 4 (fewer elements are stepped one by one: the ragged head of a row range).
  */
 /* One training step of the TABLE in one call (single-GPU steps): naf_render_train whose gradient reducer applies the Adam
  * update to the table rows it has just finished instead of writing their gradient out for naf_adam_step to read back and
@@ -327,6 +328,43 @@ int naf_render_train_adam(const float *rays, const float *t_rand, const float *t
                           const void *embeddings, const int32_t *offsets, const float *mlp, float *acc, float *grad_embeddings,
                           float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
                           const naf_table_adam *adam, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Level-parallel training for small steps on several GPUs (one process per GPU; no counterpart in the reference, which has no
+ * distributed code -- it shards trainer.py:134-142 around train.py:48-135 like the data-parallel step does, with the same result).
+ * Rank k of N owns the levels [k L/N, (k+1) L/N) of the table: their rows, Adam moments and 16-bit shadow.  A step is
+ *   1. naf_levels_encode       the owned levels of EVERY rank's sample points      -> features [owned levels][all points][C]
+ *      all-to-all (RCCL, xGMI point to point): every rank receives all L levels of ITS points, [L][own points][C]
+ *   2. naf_levels_field_step   MLP forward, loss, MLP backward on the own rays      -> feature gradients [L][own points][C],
+ *                              grad_mlp (+=), loss_out (+=)   (summed over ranks by a 17 KB all-reduce)
+ *      all-to-all back: every rank receives the gradients of its levels for every rank's points, one block per source rank
+ *   3. naf_levels_scatter      table-gradient scatter of the owned levels over all points, Adam on their rows
+ * Per rank and step 2 x (N-1)/N x points x L x C x 2 B cross the links (25 MB at the reference's 1 024 rays x 192 samples) instead
+ * of the (N-1)/N x (57 + 28.5) MB a gradient exchange of the T = 2^19 table needs whatever the batch, and the optimiser pass shrinks
+ * to 1/N of the table.  Above ~3 000 rays per GPU and step the gradient exchange is the smaller one (engine.py picks).
+ * `rays` of calls 1 and 3 are all ranks' rays in rank order, cfg->ray_index_base the global index of the first of them, so that
+ * every point gets the jitter the rank that renders it uses.  Features are bf16 (mlp_precision NAF_BF16) or fp32 (NAF_F32). */
+
+/* features[(l - level_begin) * B + b][C] for l in [level_begin, level_end), B = n_rays * n_samples points. */
+int naf_levels_encode(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets, void *features,
+                      uint32_t n_rays, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end, void *stream);
+
+/* features / feature_grads: [L][B][C] of the n_rays own rays.  acc[n_rays] is written; grad_mlp (+=), loss_out[0] (+=) as in
+ * naf_render_train.  `workspace`: naf_render_workspace_bytes(cfg, B). */
+int naf_levels_field_step(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
+                          const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                          const naf_render_cfg *cfg, void *workspace, void *stream);
+
+/* grad_blocks: n_ranks blocks `block_stride_bytes` apart, block r = [level_end - level_begin][B / n_ranks][C] feature gradients of
+ * rank r's points (what the all-to-all delivers); n_rays = all ranks' rays (a multiple of n_ranks), `workspace`:
+ * naf_render_workspace_bytes(cfg, B).  grad_embeddings (+=) receives the gradient of the owned levels' rows -- unless `adam` is
+ * given and the reducer can apply the update itself (as in naf_render_train_adam; *adam_applied = 1): then the rows of the owned
+ * levels in adam->param / exp_avg / exp_avg_sq / param_lp are stepped and grad_embeddings stays zero.  With *adam_applied = 0
+ * the caller steps those rows with naf_adam_step.  adam->mlp_* are ignored (the MLP is replicated: its gradient is all-reduced). */
+int naf_levels_scatter(const float *rays, const float *t_rand, const void *grad_blocks, size_t block_stride_bytes, uint32_t n_ranks,
+                       const int32_t *offsets, float *grad_embeddings, uint32_t n_rays, const naf_render_cfg *cfg,
+                       uint32_t level_begin, uint32_t level_end, void *workspace, const naf_table_adam *adam, int *adam_applied,
+                       void *stream);
 
 int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, float *grad, void *param_lp, int lp_dtype,
                   uint64_t n, float lr, float beta1, float beta2, float eps, uint32_t step, float grad_scale,

@@ -80,7 +80,8 @@ extern "C" int naf_adam_step(float *param, float *exp_avg, float *exp_avg_sq, fl
                              int zero_grad, void *stream) {
     if (n != 0 && (!param || !exp_avg || !exp_avg_sq || !grad)) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: null pointer");
     if (step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: step is 1-based");
-    if (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad) & 15u)
+    // (fewer than four elements take the scalar tail of the kernel: the ragged head of a row range that starts inside a 16-byte group)
+    if (n >= 4 && (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad) & 15u))
         return fail(NAF_ERR_INVALID_ARGUMENT, "adam_step: buffers must be 16-byte aligned");
     return launch_adam(param, exp_avg, exp_avg_sq, grad, param_lp, lp_dtype, n, make_adam_args(lr, beta1, beta2, eps, step, grad_scale),
                        zero_grad != 0, (hipStream_t)stream);

@@ -1009,8 +1009,13 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
 }
 
 template <typename TT, typename P, uint32_t C, typename Src>
-static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s,
+                      uint32_t lv_begin = 0u, uint32_t lv_end = ~0u) {
+    // [lv_begin, lv_end): the levels to encode (all by default; a level-parallel rank encodes the levels it owns, naf_levels_encode).
+    // `feat` is indexed by the ABSOLUTE level either way: level l of point b sits at (l * B + b) * C.
     using FT = typename P::feat_t;
+    lv_end = std::min(lv_end, cfg->L);
+    const uint32_t nl = lv_end - lv_begin;
     constexpr bool kCanWindow = PairWindow<TT, C>::kUsable;
     // x-neighbour corners through ONE 16-byte window per pair (fewer L1 accesses: what small batches are bound by) or through two
     // gathers with four points per lane in flight (more misses outstanding: what large batches are bound by).  Measured
@@ -1025,7 +1030,7 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
     if (per_level_launches(cfg)) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
-        for (uint32_t l = 0; l < cfg->L; ++l) {
+        for (uint32_t l = lv_begin; l < lv_end; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
                                (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L, 0u);
@@ -1043,20 +1048,22 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     if ((cfg->flags & (NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) != 0u)
         log2g = ((cfg->flags & NAF_CFG_ENCODE_GROUPS_2) != 0u ? 1u : 0u) + ((cfg->flags & NAF_CFG_ENCODE_GROUPS_4) != 0u ? 2u : 0u);
     if ((cfg->flags & NAF_CFG_ENCODE_LEVEL_MAJOR) != 0u) log2g = 0u;
-    const bool grouped = !interleaved && log2g != 0u && cfg->L % (1u << log2g) == 0u && cfg->L >= 8u;
+    while (log2g != 0u && nl % (1u << log2g) != 0u) --log2g;                 // a level range: as many groups as divide it
+    const bool grouped = !interleaved && log2g != 0u && (nl >= 8u || nl != cfg->L);
     const uint32_t order = interleaved ? 1u : grouped ? 4u + log2g : 0u;
-    const dim3 grid = interleaved ? dim3(cfg->L, gx) : grouped ? dim3((cfg->L * gx + 7u) / 8u * 8u) : dim3(gx, cfg->L);
+    const dim3 grid = interleaved ? dim3(nl, gx) : grouped ? dim3((nl * gx + 7u) / 8u * 8u) : dim3(gx, nl);
     { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, 0u, order, cfg->L, cfg->L, gx); }
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, lv_begin, order, nl, cfg->L, gx); }
     return check_launch("encode_kernel");
 }
 
 template <typename P, uint32_t C, typename Src>
-static int dispatch_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s) {
+static int dispatch_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s,
+                           uint32_t lv_begin = 0u, uint32_t lv_end = ~0u) {
     switch (cfg->table_dtype) {
-        case NAF_F32: return run_encode<F32, P, C>(src, table, offsets, feat, B, cfg, s);
-        case NAF_F16: return run_encode<F16, P, C>(src, table, offsets, feat, B, cfg, s);
-        default: return run_encode<BF16, P, C>(src, table, offsets, feat, B, cfg, s);
+        case NAF_F32: return run_encode<F32, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
+        case NAF_F16: return run_encode<F16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
+        default: return run_encode<BF16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
     }
 }
 
@@ -1394,6 +1401,117 @@ static int field_forward_grid_impl(const SrcGrid &src, const void *emb, const in
     return run_mlp_forward<P, C, false>(ws, mlp, none, sigma, B, B, cfg, s, nullptr, nullptr, omap);
 }
 
+// ---- level-parallel training (naf_levels_*, naf_hip.h): each rank owns a range of levels ----------------------------------
+// Feature gradients arrive from the all-to-all as one block per source rank, [rank][owned level][that rank's points][C]; the
+// scatter wants [level][all points][C].  One pass moves them there (16 bytes per lane where the block length allows it), takes
+// the maximum |gradient| the fixed-point reducer scales by (the MLP backward of a single-GPU step hands that over; here it ran on
+// other GPUs) -- as the bit pattern of the fp32 value, so that NaN / Inf poison the step as they do there.
+template <typename T> __device__ __forceinline__ uint32_t abs_bits(T raw);
+template <> __device__ __forceinline__ uint32_t abs_bits<uint16_t>(uint16_t raw) { return ((uint32_t)raw << 16) & 0x7fffffffu; }      // bf16
+template <> __device__ __forceinline__ uint32_t abs_bits<uint32_t>(uint32_t raw) { return raw & 0x7fffffffu; }                        // fp32
+
+template <typename T, bool kVec>
+__global__ void __launch_bounds__(256)
+levels_gather_kernel(const unsigned char *__restrict__ blocks, size_t block_stride, T *__restrict__ dst, uint32_t n_ranks, uint32_t nl, uint32_t run,
+                     uint32_t lv_begin, uint32_t *__restrict__ gmax_bits) {
+    // run = elements of one (rank, level): points of a rank x C.  dst[(lv_begin + l) * n_ranks * run + r * run + i] = block_r[l * run + i]
+    constexpr uint32_t kPer = kVec ? 16u / sizeof(T) : 1u;
+    const uint64_t units_per_run = run / kPer, total = (uint64_t)n_ranks * nl * units_per_run;
+    uint32_t m = 0u;
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(u / ((uint64_t)nl * units_per_run));
+        const uint64_t rem = u - (uint64_t)r * nl * units_per_run;
+        const uint32_t l = (uint32_t)(rem / units_per_run);
+        const uint64_t i = (rem - (uint64_t)l * units_per_run) * kPer;
+        const T *src = reinterpret_cast<const T *>(blocks + (size_t)r * block_stride) + (size_t)l * run + i;
+        T *out = dst + ((size_t)(lv_begin + l) * n_ranks + r) * run + i;
+        if constexpr (kVec) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src);
+            *reinterpret_cast<uint4 *>(out) = q;
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if constexpr (sizeof(T) == 2) m = max(m, max(abs_bits<uint16_t>((uint16_t)(w[k] & 0xffffu)), abs_bits<uint16_t>((uint16_t)(w[k] >> 16))));
+                else m = max(m, abs_bits<uint32_t>(w[k]));
+            }
+        } else {
+            const T v = *src;
+            *out = v;
+            m = max(m, abs_bits<T>(v));
+        }
+    }
+#pragma unroll
+    for (uint32_t off = 32u; off != 0u; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off));
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m != 0u) atomicMax(gmax_bits, m);                    // one per workgroup
+    }
+}
+
+static bool adam_tail_possible_levels(const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end) {
+    if (!w.binned || per_level_launches(cfg)) return false;
+    const uint32_t NB = 1u << w.plan.log2_nb;
+    for (uint32_t l0 = lv_begin; l0 < lv_end; l0 += w.plan.levels_per_pass)
+        if (reducer_split(NB, std::min(w.plan.levels_per_pass, lv_end - l0)) != 1u) return false;
+    return true;
+}
+
+template <typename P, uint32_t C>
+static int levels_encode_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, void *features, uint32_t n_rays,
+                              const naf_render_cfg *cfg, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
+    const uint32_t B = n_rays * cfg->n_samples;
+    const SrcRays src = make_src(rays, t_rand, cfg);
+    // the encoder indexes its output by the absolute level: hand it the address level 0 would have (never dereferenced below `features`)
+    const size_t esz = sizeof(typename P::feat_t::store_t);
+    void *base = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(features) - (uintptr_t)((size_t)lv_begin * B * C * esz));
+    return dispatch_encode<P, C>(src, emb, offsets, base, B, cfg, s, lv_begin, lv_end);
+}
+
+template <typename P, uint32_t C>
+static int levels_field_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
+                             const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                             const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+    const uint32_t B = n_rays * cfg->n_samples;
+    const Workspace w = carve(ws, cfg, B);
+    const SrcRays src = make_src(rays, t_rand, cfg);
+    if (int rc = run_mlp_forward<P, C, true>(features, mlp, src, acc, n_rays, B, cfg, s)) return rc;
+    const LossInputs loss{acc, target, ray_weight};
+    const StepExtras ex{nullptr, false, nullptr};
+    return run_mlp_backward<P, C>(features, mlp, src, nullptr, loss, feature_grads, w.slabs, nullptr, grad_mlp, loss_out, nullptr, n_rays, B, cfg, ex, s);
+}
+
+template <typename P, uint32_t C>
+static int levels_scatter_impl(const float *rays, const float *t_rand, const void *blocks, size_t block_stride, uint32_t n_ranks,
+                               const int32_t *offsets, float *grad_emb, uint32_t n_rays, const naf_render_cfg *cfg, uint32_t lv_begin,
+                               uint32_t lv_end, void *ws, const AdamTail *adam, int *adam_applied, hipStream_t s) {
+    using T = typename RawWord<sizeof(typename P::feat_t::store_t)>::type;          // the gradients as raw 16- or 32-bit words
+    const uint32_t B = n_rays * cfg->n_samples, nl = lv_end - lv_begin;
+    const Workspace w = carve(ws, cfg, B);
+    const SrcRays src = make_src(rays, t_rand, cfg);
+    const uint32_t run = B / n_ranks * C;                                        // elements of one (rank, level)
+    uint32_t *gmax = w.binned ? w.gmax : reinterpret_cast<uint32_t *>(w.grad_acc);      // (the atomic scatter has no use for it)
+    if (w.binned) {
+        if (hipMemsetAsync(w.overflow, 0, 34 * sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");      // counters + maximum
+    } else if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");
+    const bool vec = (run * sizeof(T)) % 16u == 0u && block_stride % 16u == 0u && ((uintptr_t)blocks & 15u) == 0u && ((uintptr_t)w.dfeat & 15u) == 0u;
+    const uint64_t units = (uint64_t)n_ranks * nl * (vec ? run / (16u / sizeof(T)) : run);
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + 255) / 256, 256u * 8u));
+    {
+        ProfScope prof_("levels_gather_kernel", s);
+        if (vec) hipLaunchKernelGGL((levels_gather_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
+        else hipLaunchKernelGGL((levels_gather_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
+    }
+    if (int rc = check_launch("levels_gather_kernel")) return rc;
+    AdamTail tail;
+    const bool fuse = adam != nullptr && adam_tail_possible_levels(cfg, w, lv_begin, lv_end);
+    if (fuse) { tail = *adam; tail.overflow = w.overflow; }
+    if (adam_applied != nullptr) *adam_applied = fuse ? 1 : 0;
+    return run_hash_backward_levels<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, lv_begin, lv_end, s, nullptr, fuse ? &tail : nullptr, nullptr);
+}
+
 #define NAF_DISPATCH_PC(FN, ...)                                                                      \
     do {                                                                                              \
         if (cfg->mlp_precision == NAF_F32) {                                                          \
@@ -1587,6 +1705,72 @@ extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, con
                                     n_rays, cfg, workspace, nullptr, stream, nullptr, mp, true)) return rc;
     return launch_adam(adam->param, adam->exp_avg, adam->exp_avg_sq, grad_embeddings, adam->param_lp, adam->lp_dtype, adam->n, tail.a,
                        true, (hipStream_t)stream);
+}
+
+/* ---- level-parallel training (naf_hip.h) --------------------------------------------------------------------------------- */
+static int check_levels(const naf_render_cfg *cfg, uint32_t lv_begin, uint32_t lv_end, const char *who) {
+    if (lv_begin >= lv_end || lv_end > cfg->L) { (void)who; return fail(NAF_ERR_INVALID_ARGUMENT, "levels: empty or out-of-range level range"); }
+    return NAF_OK;
+}
+
+extern "C" int naf_levels_encode(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets, void *features,
+                                 uint32_t n_rays, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end, void *stream) {
+    if (int rc = check_cfg(cfg, "levels_encode")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
+    if (int rc = check_levels(cfg, level_begin, level_end, "levels_encode")) return rc;
+    if (n_rays != 0 && (!rays || !embeddings || !offsets || !features)) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_encode: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_encode: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    NAF_DISPATCH_PC(levels_encode_impl, rays, t_rand, embeddings, offsets, features, n_rays, cfg, level_begin, level_end, (hipStream_t)stream);
+}
+
+extern "C" int naf_levels_field_step(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
+                                     const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                     const naf_render_cfg *cfg, void *workspace, void *stream) {
+    if (int rc = check_cfg(cfg, "levels_field_step")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
+    if (n_rays == 0) return NAF_OK;
+    if (!rays || !target || !ray_weight || !features || !mlp || !acc || !feature_grads || !grad_mlp || !loss_out || !workspace)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "levels_field_step: null pointer");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_field_step: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    NAF_DISPATCH_PC(levels_field_impl, rays, t_rand, target, ray_weight, features, mlp, acc, feature_grads, grad_mlp, loss_out, n_rays, cfg,
+                    workspace, (hipStream_t)stream);
+}
+
+extern "C" int naf_levels_scatter(const float *rays, const float *t_rand, const void *grad_blocks, size_t block_stride_bytes, uint32_t n_ranks,
+                                  const int32_t *offsets, float *grad_embeddings, uint32_t n_rays, const naf_render_cfg *cfg,
+                                  uint32_t level_begin, uint32_t level_end, void *workspace, const naf_table_adam *adam, int *adam_applied,
+                                  void *stream) {
+    if (adam_applied != nullptr) *adam_applied = 0;
+    if (int rc = check_cfg(cfg, "levels_scatter")) return rc;
+    if (int rc = check_depths(cfg, t_rand)) return rc;
+    if (int rc = check_levels(cfg, level_begin, level_end, "levels_scatter")) return rc;
+    if (n_rays == 0) return NAF_OK;
+    if (!rays || !grad_blocks || !offsets || !grad_embeddings || !workspace) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: null pointer");
+    if (n_ranks == 0 || n_rays % n_ranks != 0) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: every rank must contribute the same number of rays");
+    if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: n_samples must be >= 2");
+    if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
+    const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
+    if (block_stride_bytes < (size_t)(level_end - level_begin) * (n_rays / n_ranks) * cfg->n_samples * cfg->C * esz || block_stride_bytes % esz != 0)
+        return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: block stride smaller than a rank's block");
+    AdamTail tail;
+    const AdamTail *tp = nullptr;
+    if (adam != nullptr) {
+        if (!adam->param || !adam->exp_avg || !adam->exp_avg_sq) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: null optimiser state");
+        if (adam->step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: step is 1-based");
+        if (adam->param_lp != nullptr && adam->lp_dtype != NAF_F16 && adam->lp_dtype != NAF_BF16)
+            return fail(NAF_ERR_UNSUPPORTED, "levels_scatter: lp_dtype must be NAF_F16 or NAF_BF16 when param_lp is given");
+        if (((uintptr_t)adam->param | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq | (uintptr_t)grad_embeddings) & 15u)
+            return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: buffers must be 16-byte aligned");
+        tail.param = adam->param; tail.m = adam->exp_avg; tail.v = adam->exp_avg_sq;
+        tail.lp = adam->param_lp; tail.lp_dtype = adam->lp_dtype; tail.overflow = nullptr;
+        tail.a = make_adam_args(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale);
+        tp = &tail;
+    }
+    NAF_DISPATCH_PC(levels_scatter_impl, rays, t_rand, grad_blocks, block_stride_bytes, n_ranks, offsets, grad_embeddings, n_rays, cfg, level_begin,
+                    level_end, workspace, tp, adam_applied, (hipStream_t)stream);
 }
 
 extern "C" int naf_field_forward(const float *pts, const void *embeddings, const int32_t *offsets, const float *mlp,

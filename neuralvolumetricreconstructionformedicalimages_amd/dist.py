@@ -69,6 +69,20 @@ def global_mean_weights(mask, group=None):
 SINGLE_BUCKET_BELOW_POINTS = 1 << 20
 
 
+def pick_dp_mode(world, num_levels, level_dim, table_elements, points_per_step, feature_bytes=2, table_bytes=2):
+    """'levels' or 'sharded' for a multi-GPU run, by the bytes a rank puts on the links per step (x (N-1)/N either way):
+    level-parallel = two all-to-alls of points x L x C features / feature gradients; sharded data-parallel = reduce-scatter of the
+    fp32 table gradient + all-gather of the table the kernels read.  At the reference's 1 024 rays x 192 samples (chest, bf16):
+    25 MB against 85.5 MB -- and level-parallel ranks also run only 1/N of the optimiser pass, the largest kernel of a step that
+    size; from ~3 300 rays per GPU and step on the gradient exchange is the smaller one.  Level-parallel needs a world size that
+    divides the number of levels."""
+    if world <= 1 or points_per_step is None or num_levels % world != 0:
+        return "sharded"
+    levels_bytes = 2 * int(points_per_step) * num_levels * level_dim * feature_bytes
+    sharded_bytes = int(table_elements) * (4 + table_bytes)
+    return "levels" if levels_bytes < sharded_bytes else "sharded"
+
+
 def default_bucket_levels(num_levels, points_per_step=None):
     """Level ranges in the order the gradient scatter finishes them: the fine half, then the coarse half (one range for small steps).
     Two buckets of L/2 levels keep every reducer launch UNSPLIT (64 row buckets x 8 levels = 512 workgroups: a workgroup is the

@@ -40,13 +40,20 @@ class NAFEngine:
         self.step_count = 0
         self.rays_seen = 0
         self.process_group = process_group
-        if dp_mode not in ("sharded", "allreduce"):
-            raise ValueError("dp_mode must be 'sharded' (reduce-scatter, per-rank Adam on a table slice, all-gather) or 'allreduce'")
-        self.dp_mode = dp_mode
+        if dp_mode not in ("auto", "sharded", "allreduce", "levels"):
+            raise ValueError("dp_mode must be 'sharded' (reduce-scatter, per-rank Adam on a table slice, all-gather), 'allreduce', "
+                             "'levels' (each rank owns a range of levels; features and their gradients cross in two all-to-alls) or 'auto'")
         self.world, self.rank = 1, 0
         if process_group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        if dp_mode == "auto":
+            from . import dist as naf_dist
+            pts = None if rays_per_step_hint is None else int(rays_per_step_hint) * int(n_samples)
+            feat_bytes = 4 if (mlp_precision == _abi.F32 or (mlp_precision is None and table_dtype == torch.float32)) else 2
+            dp_mode = naf_dist.pick_dp_mode(self.world, enc.num_levels, enc.level_dim, enc.embeddings.numel(), pts, feat_bytes,
+                                            4 if table_dtype == torch.float32 else 2)
+        self.dp_mode = dp_mode
         self.scatter_mode, self.cfg_flags = scatter_mode, cfg_flags     # None: fused.scatter_mode() default (auto)
         # single-GPU, single-stream steps let the gradient reducer apply the table's Adam update itself (naf_render_train_adam:
         # the gradient table is neither written, re-read nor cleared; bit-identical to backward() + optimizer_step())
@@ -94,11 +101,15 @@ class NAFEngine:
         # alternating HIP streams, so the gather-bound, VALU-bound and store-bound kernels of different chunks overlap.
         # Each extra stream owns a gradient buffer, a workspace and a loss cell; they are summed before Adam.
         self._dp = None
+        self._lv = None
         if process_group is not None:
             if int(n_streams) > 1:
                 raise ValueError("NAFEngine: n_streams > 1 cannot be combined with a process group (the bucket events are "
                                  "recorded by the one launch that owns the gradient buffer)")
-            self._init_data_parallel(bucket_levels, None if rays_per_step_hint is None else int(rays_per_step_hint) * self.n_samples)
+            if self.dp_mode == "levels":
+                self._init_level_parallel()
+            else:
+                self._init_data_parallel(bucket_levels, None if rays_per_step_hint is None else int(rays_per_step_hint) * self.n_samples)
         self.n_streams = max(1, int(n_streams))
         self.chunk_rays = int(chunk_rays)
         self._lanes = []
@@ -151,6 +162,127 @@ class NAFEngine:
         st.mlp_ready = dp["mlp_ready"].cuda_event
         dp["struct"] = st
         self._dp = dp
+
+    # ---- level parallel -------------------------------------------------------------------------------------
+    def _init_level_parallel(self):
+        """Rank k owns the levels [k L/N, (k+1) L/N): their rows of the table, of the 16-bit shadow and of the Adam moments are
+        current on that rank only (`gather_state` completes them everywhere before an evaluation or a checkpoint)."""
+        L, N = self.net.encoder.num_levels, self.world
+        if L % N != 0:
+            raise ValueError(f"dp_mode 'levels' needs a world size that divides the {L} levels (got {N}); use 'sharded'")
+        per = L // N
+        offs = [int(v) for v in self.offsets.tolist()]
+        C = self.net.encoder.level_dim
+
+        def event():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return ev
+        self._lv = {"levels": (self.rank * per, (self.rank + 1) * per), "per": per,
+                    "rows": [(offs[k * per] * C, offs[(k + 1) * per] * C) for k in range(N)],      # element ranges by owner
+                    "comm": torch.cuda.Stream(device=self.device), "mlp_ready": event(), "mlp_done": event(), "buf": {},
+                    "stale": False, "time": False, "timings": []}
+
+    def _all_to_all(self, out, inp):
+        """Equal-split all-to-all of two contiguous device buffers (RCCL; the gloo rehearsal of a one-GPU box stages through the host)."""
+        import torch.distributed as dist
+        if dist.get_backend(self.process_group) == "gloo" and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o.view(torch.uint8).view(-1), inp.cpu().view(torch.uint8).view(-1), group=self.process_group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.process_group)
+
+    def _train_step_levels(self, rays, target, weight, t_rand, ray_base, rays_all=None):
+        """One level-parallel step (include/naf_hip.h, naf_levels_*): encode the owned levels for every rank's points -> all-to-all
+        -> MLP forward / loss / backward on the own rays -> all-to-all of the feature gradients (+ a 17 KB all-reduce of the MLP
+        gradient and the loss behind it, overlapping the scatter) -> scatter + Adam on the owned levels.  Same result as the
+        data-parallel step and as one process on the concatenated batch.  Every rank must bring the same number of rays; the
+        jitter index of ray j of rank k is ray_base - rank * n + k * n + j (the convention ray_base = (step * world + rank) * n of
+        trainer.py / bench.py).  `rays_all` [world * n, 8]: all ranks' rays in rank order when the caller has them (a shared pixel
+        draw); otherwise they are all-gathered (32 KB per rank)."""
+        import torch.distributed as dist
+        N, r, grp, lv = self.world, self.rank, self.process_group, self._lv
+        n, S = rays.shape[0], self.n_samples
+        enc = self.net.encoder
+        L, C = enc.num_levels, enc.level_dim
+        lb, le = lv["levels"]
+        nl = le - lb
+        if n == 0:
+            raise ValueError("dp_mode 'levels': every rank needs the same, non-zero number of rays per step")
+        main = torch.cuda.current_stream(self.device)
+        if rays_all is None:
+            rays_all = torch.empty(N * n, 8, device=self.device)
+            dist.all_gather_into_tensor(rays_all, rays.contiguous(), group=grp)
+        elif rays_all.shape[0] != N * n:
+            raise ValueError("rays_all must hold world_size * n rays")
+        t_all = None
+        if t_rand is not None:
+            t_all = torch.empty(N * n, t_rand.shape[1], device=self.device)
+            dist.all_gather_into_tensor(t_all, t_rand.contiguous(), group=grp)
+        fdt = torch.float32 if int(self.mlp_precision) == _abi.F32 else torch.bfloat16
+        esz = 4 if fdt == torch.float32 else 2
+        run = n * S * C                                            # elements of one (rank, level)
+        key = (n, fdt)
+        if key not in lv["buf"]:
+            lv["buf"].clear()
+            mk = lambda *shape: torch.empty(*shape, dtype=fdt, device=self.device)
+            lv["buf"][key] = {"enc": mk(nl, N, run), "send": mk(N, nl, run), "feat": mk(L, run), "dfeat": mk(L, run), "recv": mk(N, nl * run)}
+        b = lv["buf"][key]
+        if self.acc is None or self.acc.numel() < n:
+            self.acc = torch.empty(n, device=self.device)
+        cfg_all, cfg = self._cfg((ray_base - r * n) & 0xffffffff), self._cfg(ray_base)
+        ws = fused.workspace(cfg_all, N * n * S, self.device)
+        lib, sp = _abi.lib(), _abi.stream_ptr()
+        marks = []
+
+        def mark():
+            if lv["time"]:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(main)
+                marks.append(ev)
+        mark()
+        _abi.check(lib.naf_levels_encode(_abi.ptr(rays_all), _abi.ptr(t_all), _abi.ptr(self.table), _abi.ptr(self.offsets), _abi.ptr(b["enc"]),
+                                         N * n, ctypes.byref(cfg_all), lb, le, sp), "levels_encode")
+        b["send"].copy_(b["enc"].transpose(0, 1))                   # [level][rank][points] -> one block per destination rank
+        mark()
+        self._all_to_all(b["feat"], b["send"])                      # block k of the result = rank k's levels of MY points: [L][points][C]
+        mark()
+        self.loss.zero_()
+        _abi.check(lib.naf_levels_field_step(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(b["feat"]),
+                                             _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(b["dfeat"]), _abi.ptr(self.mlp_g),
+                                             _abi.ptr(self.loss), n, ctypes.byref(cfg), _abi.ptr(ws), sp), "levels_field_step")
+        lv["mlp_ready"].record(main)
+        mark()
+        self._all_to_all(b["recv"], b["dfeat"])                     # block k = rank k's gradients of MY levels
+        mark()
+        with torch.cuda.stream(lv["comm"]):                         # issued after the all-to-all, so it queues behind it on the links
+            lv["comm"].wait_event(lv["mlp_ready"])
+            o_mlp = self._emb_flat.numel()
+            dist.all_reduce(self.grad_flat[o_mlp:], group=grp)      # MLP gradient + loss
+            lv["mlp_done"].record(lv["comm"])
+        self.step_count += 1
+        b1, b2 = self.betas
+        st = _abi.TableAdam()
+        st.param, st.exp_avg, st.exp_avg_sq = self.emb.data_ptr(), self.emb_m.data_ptr(), self.emb_v.data_ptr()
+        st.param_lp = None if self.emb_lp is None else self.emb_lp.data_ptr()
+        st.lp_dtype = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
+        st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = self.emb.numel(), self.lr, b1, b2, self.eps, self.step_count, 1.0
+        applied = ctypes.c_int(0)
+        _abi.check(lib.naf_levels_scatter(_abi.ptr(rays_all), _abi.ptr(t_all), _abi.ptr(b["recv"]), nl * run * esz, N, _abi.ptr(self.offsets),
+                                          _abi.ptr(self.emb_g), N * n, ctypes.byref(cfg_all), lb, le, _abi.ptr(ws), ctypes.byref(st),
+                                          ctypes.byref(applied), sp), "levels_scatter")
+        if not applied.value:
+            # the reducer launches were split (few levels per rank) or the batch took the atomic scatter: the gradient of the owned
+            # rows sits in emb_g
+            self._adam_rows(*lv["rows"][r], what="adam_step(owned levels)")
+        main.wait_event(lv["mlp_done"])
+        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
+        mark()
+        if lv["time"]:
+            lv["timings"].append(marks)
+        lv["stale"] = N > 1
+        fused._bump(self.device)
 
     def broadcast_parameters(self, src=0):
         """Every rank starts from rank `src`'s table and MLP (and refreshes its 16-bit shadow)."""
@@ -269,6 +401,17 @@ class NAFEngine:
         _abi.check(_abi.lib().naf_adam_step(_abi.ptr(param), _abi.ptr(m), _abi.ptr(v), _abi.ptr(g), _abi.ptr(lp), lp_code,
                                             param.numel(), self.lr, b1, b2, self.eps, self.step_count, grad_scale, 1,
                                             _abi.stream_ptr()), what)
+
+    def _adam_rows(self, a, e, what="adam_step(table rows)"):
+        """Adam on the elements [a, e) of the flat table (master, moments, gradient, 16-bit shadow), gradient cleared: a ragged head
+        of up to three elements one by one, the rest in 16-byte groups."""
+        lp_code = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
+        emb, m, v, g = (t.view(-1) for t in (self.emb, self.emb_m, self.emb_v, self.emb_g))
+        lp = None if self.emb_lp is None else self.emb_lp.view(-1)
+        head = min(e, a + (-a) % 4)
+        for lo, hi in ((a, head), (head, e)):
+            if hi > lo:
+                self._adam(emb[lo:hi], m[lo:hi], v[lo:hi], g[lo:hi], None if lp is None else lp[lo:hi], lp_code, what)
 
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
@@ -397,6 +540,14 @@ class NAFEngine:
         """Sharded data-parallel training keeps the fp32 master (16-bit mode) and the Adam moments current only on the rank that
         owns a slice.  Collective: every rank calls it (before an evaluation or a checkpoint, trainer.py:113-126) and ends up
         with the complete master table and moments.  A no-op for single-process and all-reduce training."""
+        if self.dp_mode == "levels" and self.world > 1:
+            import torch.distributed as dist
+            flats = [self.emb.view(-1), self.emb_m.view(-1), self.emb_v.view(-1)] + ([] if self.emb_lp is None else [self.emb_lp.view(-1)])
+            for k, (a, e) in enumerate(self._lv["rows"]):           # every owner hands out its rows
+                for t in flats:
+                    dist.broadcast(t[a:e], src=dist.get_global_rank(self.process_group, k), group=self.process_group)
+            self._lv["stale"] = False
+            return
         if self._dp is None or self.dp_mode != "sharded" or self.world == 1:
             return
         import torch.distributed as dist
@@ -420,11 +571,21 @@ class NAFEngine:
         """Switch on event timing of the exchange (bench.py); `comm_report()` then returns per-step averages."""
         if self._dp is not None:
             self._dp["time"], self._dp["timings"] = bool(enable), []
+        if self._lv is not None:
+            self._lv["time"], self._lv["timings"] = bool(enable), []
 
     def comm_report(self):
         """-> {"allreduce_ms_per_step": time the collectives were in flight on the side stream (sum over buckets),
         "exposed_ms_per_step": time the main stream spent between the end of its own compute and the last Adam launch minus the
         Adam kernels themselves, i.e. what the exchange adds to the step}.  Synchronises."""
+        if self._lv is not None and self._lv["timings"]:
+            torch.cuda.synchronize(self.device)
+            steps = self._lv["timings"]
+            names = ("encode_ms", "features_all_to_all_ms", "field_ms", "gradients_all_to_all_ms", "scatter_adam_ms")
+            out = {k: sum(m[i].elapsed_time(m[i + 1]) for m in steps) / len(steps) for i, k in enumerate(names)}
+            out["allreduce_ms_per_step"] = out["features_all_to_all_ms"] + out["gradients_all_to_all_ms"]
+            out["tail_ms_per_step"] = out["allreduce_ms_per_step"]
+            return out
         if self._dp is None or not self._dp["timings"]:
             return None
         torch.cuda.synchronize(self.device)
@@ -443,7 +604,7 @@ class NAFEngine:
                                               float(self.net.bound), cfg.seed, int(ray_base), _abi.stream_ptr()), "sample_rays")
         return z
 
-    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None):
+    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync).  `raw_noise_std` > 0 (render.py:196-199): the per-sample noise on sigma adds sum_s noise_s * dist_s to a
         ray's line integral and nothing else (render.noise_line_integral), so the step runs on target - that term; `noise`: explicit
@@ -452,7 +613,9 @@ class NAFEngine:
         if float(raw_noise_std) > 0.0 and n > 0:
             from .render import noise_line_integral
             target = target - noise_line_integral(rays, self.sample_depths(rays, t_rand, ray_base), raw_noise_std, noise)
-        if self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
+        if self.dp_mode == "levels" and self.process_group is not None:
+            self._train_step_levels(rays, target, weight, t_rand, ray_base, rays_all)
+        elif self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
             self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
         else:
             self.backward(rays, target, weight, t_rand, ray_base)

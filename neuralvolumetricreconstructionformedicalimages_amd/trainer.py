@@ -138,6 +138,7 @@ class Trainer:
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
                                     table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group,
+                                    dp_mode=backend.get("dp_mode", "auto"),      # levels / sharded by the bytes on the links (dist.pick_dp_mode)
                                     rays_per_step_hint=-(-int(cfg["train"]["n_rays"]) // max(self.world, 1)))
             self.engine.broadcast_parameters()
             self.optimizer = _EngineOptimizer(self.engine)
@@ -190,6 +191,10 @@ class Trainer:
             pbar = None
 
         for idx_epoch in range(self.epoch_start, self.epochs + 1):
+            if self.group is not None and self.engine is not None and self.i_eval > 0 and (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs):
+                # a sharded optimiser / level-parallel run keeps master table and moments current on their owner only: complete them
+                # everywhere (collective) before rank 0 reads the parameters
+                self.engine.gather_state()
             if self.i_eval > 0 and self.rank == 0 and (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs):
                 self.net.eval()
                 with torch.no_grad():
@@ -230,6 +235,8 @@ class Trainer:
         return iter(self.train_dloader)
 
     def save_checkpoint(self, idx_epoch):
+        if self.group is not None and self.engine is not None:
+            self.engine.gather_state()                     # collective: every rank enters save_checkpoint
         if self.rank != 0:                                 # replicas are identical; rank 0 writes
             return
         if osp.exists(self.ckptdir):

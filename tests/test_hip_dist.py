@@ -35,7 +35,7 @@ def _batch(n=256, S=64):
 _TABLES = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
 
-def _worker(rank, world, port, out, dp_mode, table, backend="gloo"):
+def _worker(rank, world, port, out, dp_mode, table, backend="gloo", jitter="explicit"):
     """backend "gloo": every rank on GPU 0 (the one-GPU test box); "nccl": RCCL, rank r on GPU r (a multi-GPU node)."""
     local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
@@ -57,7 +57,12 @@ def _worker(rank, world, port, out, dp_mode, table, backend="gloo"):
     b, e = dist.shard_range(rays.shape[0], rank, world)
     for _ in range(3):
         w = dist.global_mean_weights(mask[b:e].cuda(), group)
-        engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, t_rand=t_rand[b:e].cuda().contiguous())
+        if jitter == "explicit":
+            engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, t_rand=t_rand[b:e].cuda().contiguous())
+        else:                                                     # counter-based jitter keyed by the global ray index
+            engine.train_step(rays[b:e].cuda(), target[b:e].cuda(), w, ray_base=b)
+    if dp_mode == "levels":
+        engine.gather_state()                                     # level-parallel ranks read only the levels they own between steps
     read = engine.table.float().cpu().numpy()                     # what the next forward would gather from (all-gathered)
     engine.gather_state()                                         # collective: complete fp32 master + moments on every rank
     torch.cuda.synchronize()
@@ -66,16 +71,19 @@ def _worker(rank, world, port, out, dp_mode, table, backend="gloo"):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("dp_mode,table", [("sharded", "fp32"), ("sharded", "bf16"), ("allreduce", "fp32"), ("allreduce", "bf16")])
-def test_two_rank_training_equals_single_process(dp_mode, table):
-    """Two ranks (gloo, sharing the test box's GPU) against one process on the concatenated batch, for both forms of the
-    exchange: all-reduce + replicated Adam, and reduce-scatter -> Adam on the rank's table slice -> all-gather (sharded)."""
+@pytest.mark.parametrize("dp_mode,table,jitter", [("sharded", "fp32", "explicit"), ("sharded", "bf16", "explicit"), ("allreduce", "fp32", "explicit"),
+                                                  ("allreduce", "bf16", "explicit"), ("levels", "fp32", "explicit"), ("levels", "bf16", "counter"),
+                                                  ("sharded", "bf16", "counter")])
+def test_two_rank_training_equals_single_process(dp_mode, table, jitter):
+    """Two ranks (gloo, sharing the test box's GPU) against one process on the concatenated batch, for the three forms of the
+    exchange: all-reduce + replicated Adam, reduce-scatter -> Adam on the rank's table slice -> all-gather (sharded), and
+    level-parallel (each rank owns half the levels; features and their gradients cross in two all-to-alls)."""
     from neuralvolumetricreconstructionformedicalimages_amd import dist
     from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, dp_mode, table)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, dp_mode, table, "gloo", jitter)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(collect(procs, q, len(procs)), key=lambda t: t[0])
@@ -89,7 +97,7 @@ def test_two_rank_training_equals_single_process(dp_mode, table):
     rays, t_rand, target, mask = _batch(S=S)
     for _ in range(3):
         w = dist.global_mean_weights(mask.cuda(), None)
-        engine.train_step(rays.cuda(), target.cuda(), w, t_rand=t_rand.cuda())
+        engine.train_step(rays.cuda(), target.cuda(), w, t_rand=t_rand.cuda() if jitter == "explicit" else None)
     emb, mlp, loss = engine.emb.cpu().numpy(), engine.mlp.cpu().numpy(), float(engine.loss.item())
     for k in (1, 2, 4, 5):                                        # replicas agree: master, MLP, the table they read, moments
         assert np.array_equal(results[0][k], results[1][k]), k
@@ -104,7 +112,7 @@ def test_two_rank_training_equals_single_process(dp_mode, table):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device); the one-GPU "
                                                             "test box runs the gloo variant above")
-@pytest.mark.parametrize("dp_mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("dp_mode", ["sharded", "allreduce", "levels"])
 def test_two_gpu_rccl_training_equals_single_process(dp_mode):
     """The same comparison over RCCL with one rank per GPU -- the transport the data-parallel step is written for (bucket events
     recorded by the library, collectives on a side stream, per-shard Adam).  Skipped where only one GPU is visible."""
