@@ -140,6 +140,16 @@ class ScanSampler:
             targets.append(t)
         return (targets[0] if len(targets) == 1 else torch.cat(targets)), rays_out
 
+    def draw_ranks(self, step, n, world, rays_out, target_out=None):
+        """The draws of all `world` ranks of a step in ONE launch, in rank order (rank r: n distinct valid pixels of projection
+        (step * world + r) mod n_proj): a level-parallel rank needs every rank's rays, and a shared seed makes them local."""
+        if n > RAYS_PER_PROJECTION or world > 16:
+            raise ValueError("draw_ranks: at most 16 ranks of at most one projection's draw each")
+        lists = [self.valid[(step * world + r) % self.n_proj] for r in range(world)]
+        seed = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        _, t, _ = self.raygen.draw(lists, n, seed, projections=self.projs, rays_out=rays_out, want_pixels=False, target_out=target_out)
+        return t, rays_out
+
 
 class ChestScan:
     """chest_50 synthetic scan resident in HBM: geometry, poses, all 50 x 512 x 512 measured values, the per-projection
@@ -289,8 +299,10 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
                          "stream, per-bucket Adam) with a world-size-1 process group")
-    ap.add_argument("--dp-mode", choices=["sharded", "allreduce"], default="sharded",
-                    help="N > 1: reduce-scatter -> per-rank Adam on a table slice -> all-gather (default), or all-reduce + replicated Adam")
+    ap.add_argument("--dp-mode", choices=["auto", "levels", "sharded", "allreduce"], default="auto",
+                    help="N > 1: levels = each rank owns L/N levels, two all-to-alls of features / feature gradients per step; sharded = "
+                         "reduce-scatter of the table gradient -> per-rank Adam on a table slice -> all-gather; allreduce = all-reduce + "
+                         "replicated Adam; auto (default) = whichever puts fewer bytes on the links (levels below ~3 300 rays per GPU)")
     ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,0-8 (default: dist.default_bucket_levels -- one range below 2^20 points per step)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
@@ -350,17 +362,32 @@ def main():
                                  rays_per_step_hint=args.rays)
 
     engine = make_engine(args.precision, pg)
-    allreduce_bytes = engine.grad_flat.numel() * 4
-    dp_buckets = None if engine._dp is None else [list(b) for b in engine._dp["levels"]]
     n = args.rays
+    levels_mode = engine.dp_mode == "levels" and pg is not None
+    if levels_mode:
+        fb = 4 if args.precision == "fp32" else 2
+        allreduce_bytes = 2 * n * CHEST["n_samples"] * 32 * fb * (world - 1) // world + 4 * (engine.grad_flat.numel() - engine._emb_flat.numel())
+    else:
+        allreduce_bytes = engine.grad_flat.numel() * 4
+    dp_buckets = None if engine._dp is None else [list(b) for b in engine._dp["levels"]]
     total_steps = args.warmup + args.steps
     rays = torch.empty(n, 8, device=device)
     weight, loss_name = step_weights(n, device, world)               # N > 1: global mean over all ranks' rays
+    shared = None
+    if levels_mode and n <= RAYS_PER_PROJECTION and world <= 16:     # every rank draws the step's whole pixel set: one seed for all
+        shared = ScanSampler.__new__(ScanSampler)
+        shared.raygen, shared.projs, shared.seed, shared.n_proj, shared.valid = sampler.raygen, sampler.projs, 1234, sampler.n_proj, sampler.valid
+        rays_all = torch.empty(world * n, 8, device=device)
+        target_all = torch.empty(world * n, device=device)
 
     def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
         # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip).
         # (Drawing step k + 1 on a side stream while step k computes was measured and is not done: the event waits that order the two
         # streams cost more stream time than the 8 us launch they hide -- 0.3182 against 0.3118 ms per step.)
+        if shared is not None and eng is None:
+            shared.draw_ranks(i, n_rays, world, rays_all, target_all)
+            lo, hi = rank * n_rays, (rank + 1) * n_rays
+            return engine.train_step(rays_all[lo:hi], target_all[lo:hi], w, ray_base=(i * world + rank) * n_rays, rays_all=rays_all)
         target, _ = sampler.draw(i, n_rays, ray_buf)
         return (eng or engine).train_step(ray_buf, target, w, ray_base=(i * world + rank) * n_rays)
 
@@ -406,7 +433,8 @@ def main():
     _abi.profile_enable(False)
     comm = engine.comm_report()
     engine.comm_timing(False)
-    overflow = engine.scatter_overflow(n)
+    n_scatter = n * world if levels_mode else n               # a level-parallel rank scatters every rank's points (its levels)
+    overflow = engine.scatter_overflow(n_scatter)
 
     def timed(fn, steps, warm):
         for i in range(warm):
@@ -534,15 +562,17 @@ def main():
                                    f"drawn on the device inside the step; perturb=True; loss: {loss_name}"
                                    + ("; the operating point that reaches 35 dB volume PSNR soonest (psnr.*, profiles/round3_psnr_race_grid.jsonl)"
                                       if n == CHEST["yaml_rays"] else ""),
-                       "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "lr": engine.lr, "parallelism": f"dp{world}"},
+                       "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "lr": engine.lr, "parallelism": (f"lp{world}" if levels_mode else f"dp{world}")},
             "final_loss": final_loss, "sustained": sustained, "psnr": psnr,
-            "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n),
+            "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n_scatter),
             "library_kernels_ms_per_step": round(kernel_ms, 4),
             "profiled_pass": {"steps": prof_steps, "ms_per_step": round(prof_elapsed / prof_steps * 1e3, 4),
                               "note": "per-kernel HIP-event pairs switched on; not the timed region"},
             "allreduce_ms_per_step": None, "allreduce_exposed_ms_per_step": None, "allreduce_buckets": dp_buckets,
             "allreduce_bytes": allreduce_bytes, "rays_per_s_per_gpu": rays_total / elapsed / world,
-            "grad_exchange": None if engine._dp is None else (
+            "grad_exchange": ("level-parallel: rank k owns levels [k L/N, (k+1) L/N) -- all-to-all of the features, all-to-all of the feature "
+                              "gradients, Adam on the owned rows; MLP gradient + loss all-reduced (allreduce_bytes = bytes a rank sends per step)")
+            if levels_mode else None if engine._dp is None else (
                 "reduce-scatter of the table gradient -> Adam on this rank's 1/N slice -> all-gather of the table the kernels read; "
                 "MLP gradient + loss all-reduced" if engine.dp_mode == "sharded" else "all-reduce per level bucket, Adam replicated"),
             "roofline": roof(dominant),
@@ -555,7 +585,11 @@ def main():
             # in flight: the collectives on the side stream, measured by events inside the profiled steps.  exposed: what the main
             # stream waited after its own compute = tail (end of compute -> last Adam launched) minus the Adam kernels themselves
             out["allreduce_ms_per_step"] = round(comm["allreduce_ms_per_step"], 4)
-            out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - per_step.get("adam_kernel", 0.0)), 4)
+            if levels_mode:                              # both all-to-alls sit on the critical path; the phases of a step by HIP events
+                out["allreduce_exposed_ms_per_step"] = round(comm["tail_ms_per_step"], 4)
+                out["level_parallel_phases_ms"] = {k: round(v, 4) for k, v in comm.items() if k.endswith("_ms")}
+            else:
+                out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - per_step.get("adam_kernel", 0.0)), 4)
         if sub_records is not None:
             out["sub_records"] = sub_records
         if world == 1 and args.cpu_seconds > 0 and not args.force_dp:

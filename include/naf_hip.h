@@ -333,7 +333,7 @@ int naf_render_train_adam(const float *rays, const float *t_rand, const float *t
  * Level-parallel training for small steps on several GPUs (one process per GPU; no counterpart in the reference, which has no
  * distributed code -- it shards trainer.py:134-142 around train.py:48-135 like the data-parallel step does, with the same result).
  * Rank k of N owns the levels [k L/N, (k+1) L/N) of the table: their rows, Adam moments and 16-bit shadow.  A step is
- *   1. naf_levels_encode       the owned levels of EVERY rank's sample points      -> features [owned levels][all points][C]
+ *   1. naf_levels_encode       the owned levels of EVERY rank's sample points      -> features [rank][owned levels][its points][C]
  *      all-to-all (RCCL, xGMI point to point): every rank receives all L levels of ITS points, [L][own points][C]
  *   2. naf_levels_field_step   MLP forward, loss, MLP backward on the own rays      -> feature gradients [L][own points][C],
  *                              grad_mlp (+=), loss_out (+=)   (summed over ranks by a 17 KB all-reduce)
@@ -345,9 +345,11 @@ int naf_render_train_adam(const float *rays, const float *t_rand, const float *t
  * `rays` of calls 1 and 3 are all ranks' rays in rank order, cfg->ray_index_base the global index of the first of them, so that
  * every point gets the jitter the rank that renders it uses.  Features are bf16 (mlp_precision NAF_BF16) or fp32 (NAF_F32). */
 
-/* features[(l - level_begin) * B + b][C] for l in [level_begin, level_end), B = n_rays * n_samples points. */
+/* features: one block per destination rank, [n_ranks][level_end - level_begin][B / n_ranks][C] (what the all-to-all sends as it is);
+ * n_rays = all ranks' rays (a multiple of n_ranks), B = n_rays * n_samples points. */
 int naf_levels_encode(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets, void *features,
-                      uint32_t n_rays, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end, void *stream);
+                      uint32_t n_rays, uint32_t n_ranks, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end,
+                      void *stream);
 
 /* features / feature_grads: [L][B][C] of the n_rays own rays.  acc[n_rays] is written; grad_mlp (+=), loss_out[0] (+=) as in
  * naf_render_train.  `workspace`: naf_render_workspace_bytes(cfg, B). */

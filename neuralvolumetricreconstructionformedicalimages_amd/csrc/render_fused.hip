@@ -903,7 +903,7 @@ template <typename TT, typename FT, uint32_t C, typename Src, uint32_t kWindow> 
 __global__ void __launch_bounds__(256)
 encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
               typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, uint32_t order, uint32_t n_levels, uint32_t total_levels,
-              uint32_t tiles) {
+              uint32_t tiles, uint32_t chunk) {
     // order 0 -- level-major (large batches): blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and
     //   that level's slice of the table stays in the L2s (98.6 % hits).
     // order 1 -- NAF_CFG_LEVELS_INTERLEAVED (diagnostic): the level in x, every XCD walks levels k and k + 8 at once.
@@ -931,6 +931,15 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     const uint32_t grid_x = order >= 4u ? tiles : order == 1u ? gridDim.y : gridDim.x;
     const LevelMeta m = make_level_meta<3>(offsets, level, H);
     const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
+    // Where the C features of point b go: [level][B points] -- or, for a level-parallel rank (naf_levels_encode, chunk = points of one
+    // rank), [rank = b / chunk][level - level_base][chunk points]: one contiguous block per destination of the all-to-all.
+    const uint32_t chunk_magic = chunk != 0u ? (uint32_t)(0x100000000ull / chunk) + 1u : 0u;
+    auto slot = [&](uint32_t b) -> size_t {
+        if (chunk == 0u) return (size_t)level * B + b;
+        uint32_t r = __umulhi(b, chunk_magic);               // b / chunk, at most one too large (b < 2^31)
+        r -= r * chunk > b ? 1u : 0u;
+        return ((size_t)r * n_levels + (level - level_base)) * chunk + (b - r * chunk);
+    };
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     const uint32_t stride = grid_x * blockDim.x;
@@ -969,7 +978,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][2 * j + 1], vb[ch], a[ch]);
                 }
-                if (b < B) store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
+                if (b < B) store_vec<FT, C>(feat + slot(b) * C, a);
             }
         }
     } else {
@@ -1000,7 +1009,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
             for (uint32_t c = 0; c < 8; ++c)
 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][c], v[k][c][ch], a[ch]);
-            if (b < B) store_vec<FT, C>(feat + ((size_t)level * B + b) * C, a);
+            if (b < B) store_vec<FT, C>(feat + slot(b) * C, a);
         }
     }
     }
@@ -1010,9 +1019,10 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
 
 template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s,
-                      uint32_t lv_begin = 0u, uint32_t lv_end = ~0u) {
+                      uint32_t lv_begin = 0u, uint32_t lv_end = ~0u, uint32_t chunk = 0u) {
     // [lv_begin, lv_end): the levels to encode (all by default; a level-parallel rank encodes the levels it owns, naf_levels_encode).
-    // `feat` is indexed by the ABSOLUTE level either way: level l of point b sits at (l * B + b) * C.
+    // `feat` is indexed by the ABSOLUTE level: level l of point b sits at (l * B + b) * C -- unless `chunk` != 0 (a level range only):
+    // then the output is [b / chunk][l - lv_begin][b % chunk][C], see encode_kernel.
     using FT = typename P::feat_t;
     lv_end = std::min(lv_end, cfg->L);
     const uint32_t nl = lv_end - lv_begin;
@@ -1028,12 +1038,12 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     auto kern = encode_kernel<TT, FT, C, Src, 0u>;
     if constexpr (kCanWindow) { if (window) kern = encode_kernel<TT, FT, C, Src, 2u>; }
     const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
-    if (per_level_launches(cfg)) {
+    if (per_level_launches(cfg) && chunk == 0u) {
         static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
         for (uint32_t l = lv_begin; l < lv_end; ++l) {
             ProfScope prof_(level_name(names, l), s);
             hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L, 0u);
+                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L, 0u, 0u);
         }
         return check_launch("encode_kernel");
     }
@@ -1053,17 +1063,17 @@ static int run_encode(const Src &src, const void *table, const int32_t *offsets,
     const uint32_t order = interleaved ? 1u : grouped ? 4u + log2g : 0u;
     const dim3 grid = interleaved ? dim3(nl, gx) : grouped ? dim3((nl * gx + 7u) / 8u * 8u) : dim3(gx, nl);
     { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, lv_begin, order, nl, cfg->L, gx); }
+                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, lv_begin, order, nl, cfg->L, gx, chunk); }
     return check_launch("encode_kernel");
 }
 
 template <typename P, uint32_t C, typename Src>
 static int dispatch_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s,
-                           uint32_t lv_begin = 0u, uint32_t lv_end = ~0u) {
+                           uint32_t lv_begin = 0u, uint32_t lv_end = ~0u, uint32_t chunk = 0u) {
     switch (cfg->table_dtype) {
-        case NAF_F32: return run_encode<F32, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
-        case NAF_F16: return run_encode<F16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
-        default: return run_encode<BF16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end);
+        case NAF_F32: return run_encode<F32, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end, chunk);
+        case NAF_F16: return run_encode<F16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end, chunk);
+        default: return run_encode<BF16, P, C>(src, table, offsets, feat, B, cfg, s, lv_begin, lv_end, chunk);
     }
 }
 
@@ -1414,20 +1424,17 @@ template <typename T, bool kVec>
 __global__ void __launch_bounds__(256)
 levels_gather_kernel(const unsigned char *__restrict__ blocks, size_t block_stride, T *__restrict__ dst, uint32_t n_ranks, uint32_t nl, uint32_t run,
                      uint32_t lv_begin, uint32_t *__restrict__ gmax_bits) {
-    // run = elements of one (rank, level): points of a rank x C.  dst[(lv_begin + l) * n_ranks * run + r * run + i] = block_r[l * run + i]
+    // run = elements of one (rank, level): points of a rank x C.  dst[((lv_begin + l) * n_ranks + r) * run + i] = block_r[l * run + i];
+    // blockIdx.y = r * nl + l, the x dimension strides over the run
     constexpr uint32_t kPer = kVec ? 16u / sizeof(T) : 1u;
-    const uint64_t units_per_run = run / kPer, total = (uint64_t)n_ranks * nl * units_per_run;
+    const uint32_t r = blockIdx.y / nl, l = blockIdx.y - r * nl, units = run / kPer;
+    const T *src = reinterpret_cast<const T *>(blocks + (size_t)r * block_stride) + (size_t)l * run;
+    T *out = dst + ((size_t)(lv_begin + l) * n_ranks + r) * run;
     uint32_t m = 0u;
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(u / ((uint64_t)nl * units_per_run));
-        const uint64_t rem = u - (uint64_t)r * nl * units_per_run;
-        const uint32_t l = (uint32_t)(rem / units_per_run);
-        const uint64_t i = (rem - (uint64_t)l * units_per_run) * kPer;
-        const T *src = reinterpret_cast<const T *>(blocks + (size_t)r * block_stride) + (size_t)l * run + i;
-        T *out = dst + ((size_t)(lv_begin + l) * n_ranks + r) * run + i;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x) {
         if constexpr (kVec) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(src);
-            *reinterpret_cast<uint4 *>(out) = q;
+            const uint4 q = reinterpret_cast<const uint4 *>(src)[u];
+            reinterpret_cast<uint4 *>(out)[u] = q;
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
@@ -1435,8 +1442,8 @@ levels_gather_kernel(const unsigned char *__restrict__ blocks, size_t block_stri
                 else m = max(m, abs_bits<uint32_t>(w[k]));
             }
         } else {
-            const T v = *src;
-            *out = v;
+            const T v = src[u];
+            out[u] = v;
             m = max(m, abs_bits<T>(v));
         }
     }
@@ -1461,13 +1468,10 @@ static bool adam_tail_possible_levels(const naf_render_cfg *cfg, const Workspace
 
 template <typename P, uint32_t C>
 static int levels_encode_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, void *features, uint32_t n_rays,
-                              const naf_render_cfg *cfg, uint32_t lv_begin, uint32_t lv_end, hipStream_t s) {
+                              const naf_render_cfg *cfg, uint32_t lv_begin, uint32_t lv_end, uint32_t n_ranks, hipStream_t s) {
     const uint32_t B = n_rays * cfg->n_samples;
     const SrcRays src = make_src(rays, t_rand, cfg);
-    // the encoder indexes its output by the absolute level: hand it the address level 0 would have (never dereferenced below `features`)
-    const size_t esz = sizeof(typename P::feat_t::store_t);
-    void *base = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(features) - (uintptr_t)((size_t)lv_begin * B * C * esz));
-    return dispatch_encode<P, C>(src, emb, offsets, base, B, cfg, s, lv_begin, lv_end);
+    return dispatch_encode<P, C>(src, emb, offsets, features, B, cfg, s, lv_begin, lv_end, B / n_ranks);
 }
 
 template <typename P, uint32_t C>
@@ -1497,12 +1501,14 @@ static int levels_scatter_impl(const float *rays, const float *t_rand, const voi
         if (hipMemsetAsync(w.overflow, 0, 34 * sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");      // counters + maximum
     } else if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");
     const bool vec = (run * sizeof(T)) % 16u == 0u && block_stride % 16u == 0u && ((uintptr_t)blocks & 15u) == 0u && ((uintptr_t)w.dfeat & 15u) == 0u;
-    const uint64_t units = (uint64_t)n_ranks * nl * (vec ? run / (16u / sizeof(T)) : run);
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + 255) / 256, 256u * 8u));
+    if ((uint64_t)n_ranks * nl > 65535u) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: too many (rank, level) blocks");
+    const uint32_t units = vec ? run / (uint32_t)(16u / sizeof(T)) : run;
+    // ~2 048 workgroups in all, each lane moving a few 16-byte pieces
+    const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((units + 1023u) / 1024u, std::max<uint32_t>(1u, 2048u / (n_ranks * nl))));
     {
         ProfScope prof_("levels_gather_kernel", s);
-        if (vec) hipLaunchKernelGGL((levels_gather_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
-        else hipLaunchKernelGGL((levels_gather_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
+        if (vec) hipLaunchKernelGGL((levels_gather_kernel<T, true>), dim3(gx, n_ranks * nl), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
+        else hipLaunchKernelGGL((levels_gather_kernel<T, false>), dim3(gx, n_ranks * nl), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
     }
     if (int rc = check_launch("levels_gather_kernel")) return rc;
     AdamTail tail;
@@ -1714,7 +1720,8 @@ static int check_levels(const naf_render_cfg *cfg, uint32_t lv_begin, uint32_t l
 }
 
 extern "C" int naf_levels_encode(const float *rays, const float *t_rand, const void *embeddings, const int32_t *offsets, void *features,
-                                 uint32_t n_rays, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end, void *stream) {
+                                 uint32_t n_rays, uint32_t n_ranks, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end,
+                                 void *stream) {
     if (int rc = check_cfg(cfg, "levels_encode")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (int rc = check_levels(cfg, level_begin, level_end, "levels_encode")) return rc;
@@ -1722,7 +1729,8 @@ extern "C" int naf_levels_encode(const float *rays, const float *t_rand, const v
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_encode: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
     if (n_rays == 0) return NAF_OK;
-    NAF_DISPATCH_PC(levels_encode_impl, rays, t_rand, embeddings, offsets, features, n_rays, cfg, level_begin, level_end, (hipStream_t)stream);
+    if (n_ranks == 0 || n_rays % n_ranks != 0) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_encode: every rank must contribute the same number of rays");
+    NAF_DISPATCH_PC(levels_encode_impl, rays, t_rand, embeddings, offsets, features, n_rays, cfg, level_begin, level_end, n_ranks, (hipStream_t)stream);
 }
 
 extern "C" int naf_levels_field_step(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,

@@ -227,7 +227,7 @@ class NAFEngine:
         if key not in lv["buf"]:
             lv["buf"].clear()
             mk = lambda *shape: torch.empty(*shape, dtype=fdt, device=self.device)
-            lv["buf"][key] = {"enc": mk(nl, N, run), "send": mk(N, nl, run), "feat": mk(L, run), "dfeat": mk(L, run), "recv": mk(N, nl * run)}
+            lv["buf"][key] = {"send": mk(N, nl, run), "feat": mk(L, run), "dfeat": mk(L, run), "recv": mk(N, nl * run)}
         b = lv["buf"][key]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
@@ -242,9 +242,8 @@ class NAFEngine:
                 ev.record(main)
                 marks.append(ev)
         mark()
-        _abi.check(lib.naf_levels_encode(_abi.ptr(rays_all), _abi.ptr(t_all), _abi.ptr(self.table), _abi.ptr(self.offsets), _abi.ptr(b["enc"]),
-                                         N * n, ctypes.byref(cfg_all), lb, le, sp), "levels_encode")
-        b["send"].copy_(b["enc"].transpose(0, 1))                   # [level][rank][points] -> one block per destination rank
+        _abi.check(lib.naf_levels_encode(_abi.ptr(rays_all), _abi.ptr(t_all), _abi.ptr(self.table), _abi.ptr(self.offsets), _abi.ptr(b["send"]),
+                                         N * n, N, ctypes.byref(cfg_all), lb, le, sp), "levels_encode")      # one block per destination rank
         mark()
         self._all_to_all(b["feat"], b["send"])                      # block k of the result = rank k's levels of MY points: [L][points][C]
         mark()

@@ -46,15 +46,15 @@ def _levels_step(eng, N, rays, target, weight):
     ws = fused.workspace(cfg_all, n_all * S, eng.device)
     feats = []
     for k in range(N):                                            # every owner encodes its levels for all points
-        out = torch.full((per, N, run), float("nan"), dtype=fdt, device=eng.device)
-        _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_all,
+        out = torch.full((N, per, run), float("nan"), dtype=fdt, device=eng.device)      # one block per destination rank
+        _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_all, N,
                                          ctypes.byref(cfg_all), k * per, (k + 1) * per, sp), "levels_encode")
         feats.append(out)
     eng.loss.zero_()
     acc = torch.empty(n_all, device=eng.device)
     grads = []
     for r in range(N):                                            # "all-to-all": rank r receives every owner's levels of its points
-        feat = torch.cat([f[:, r, :] for f in feats], 0).contiguous()            # [L, run]
+        feat = torch.cat([f[r] for f in feats], 0).contiguous()                  # [L, run]
         dfeat = torch.full((L, run), float("nan"), dtype=fdt, device=eng.device)
         cfg = eng._cfg(r * n)
         sl = slice(r * n, (r + 1) * n)
@@ -131,12 +131,12 @@ def test_level_parallel_first_step_gradient_matches_the_plain_backward_fp32():
     ws = fused.workspace(cfg_all, n_rays * S, lev.device)
     feats = []
     for k in range(N):
-        out = torch.empty(per, N, run, device=lev.device)
-        _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(lev.table), _abi.ptr(lev.offsets), _abi.ptr(out), n_rays,
+        out = torch.empty(N, per, run, device=lev.device)
+        _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(lev.table), _abi.ptr(lev.offsets), _abi.ptr(out), n_rays, N,
                                          ctypes.byref(cfg_all), k * per, (k + 1) * per, sp), "levels_encode")
         feats.append(out)
     # the features are the ones the single-GPU step computes, bit for bit
-    full = torch.cat(feats, 0).reshape(L, n_rays * S * C)
+    full = torch.cat([f.transpose(0, 1) for f in feats], 0).reshape(L, n_rays * S * C)      # [level][rank][points] = [level][all points]
     ws_ref = fused.workspace(ref._cfg(0), n_rays * S, ref.device)
     want = ws_ref[:full.numel() * 4].view(torch.float32).reshape(L, -1)
     assert torch.equal(full, want)
@@ -144,7 +144,7 @@ def test_level_parallel_first_step_gradient_matches_the_plain_backward_fp32():
     acc = torch.empty(n_rays, device=lev.device)
     grads = []
     for r in range(N):
-        feat = torch.cat([f[:, r, :] for f in feats], 0).contiguous()
+        feat = torch.cat([f[r] for f in feats], 0).contiguous()
         dfeat = torch.empty(L, run, device=lev.device)
         sl = slice(r * n, (r + 1) * n)
         _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl].contiguous()), None, _abi.ptr(target[sl].contiguous()), _abi.ptr(weight[sl].contiguous()),
@@ -171,8 +171,9 @@ def test_level_parallel_entry_points_reject_bad_arguments():
     ws = fused.workspace(cfg, 16 * 32, eng.device)
     lib, sp = _abi.lib(), _abi.stream_ptr()
     out = torch.empty(16, 16 * 32 * 2, device="cuda")
-    assert lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), 16, ctypes.byref(cfg), 4, 4, sp) != 0
-    assert lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), 16, ctypes.byref(cfg), 8, 17, sp) != 0
+    assert lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), 16, 2, ctypes.byref(cfg), 4, 4, sp) != 0
+    assert lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), 16, 2, ctypes.byref(cfg), 8, 17, sp) != 0
+    assert lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), 16, 3, ctypes.byref(cfg), 0, 8, sp) != 0
     # 16 rays cannot come from 3 ranks with equal shares; a block stride shorter than a block
     assert lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(out), 4096, 3, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g), 16, ctypes.byref(cfg), 0, 8,
                                   _abi.ptr(ws), None, None, sp) != 0
