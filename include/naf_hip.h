@@ -351,11 +351,13 @@ int naf_levels_encode(const float *rays, const float *t_rand, const void *embedd
                       uint32_t n_rays, uint32_t n_ranks, const naf_render_cfg *cfg, uint32_t level_begin, uint32_t level_end,
                       void *stream);
 
-/* features / feature_grads: [L][B][C] of the n_rays own rays.  acc[n_rays] is written; grad_mlp (+=), loss_out[0] (+=) as in
- * naf_render_train.  `workspace`: naf_render_workspace_bytes(cfg, B). */
+/* features / feature_grads: [L][B][C] of the n_rays own rays.  acc[n_rays] is written; grad_mlp (+=) as in naf_render_train,
+ * loss_out[0] is OVERWRITTEN with this rank's share of the loss.  `workspace`: naf_render_workspace_bytes(cfg, B).
+ * `grads_ready` (hipEvent_t owned by the caller, or NULL) is recorded on `stream` as soon as feature_grads are final -- before the
+ * reduction that finishes grad_mlp and loss_out -- so that the all-to-all of the gradients can start behind it on another stream. */
 int naf_levels_field_step(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
                           const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                          const naf_render_cfg *cfg, void *workspace, void *stream);
+                          const naf_render_cfg *cfg, void *workspace, void *grads_ready, void *stream);
 
 /* grad_blocks: n_ranks blocks `block_stride_bytes` apart, block r = [level_end - level_begin][B / n_ranks][C] feature gradients of
  * rank r's points (what the all-to-all delivers); n_rays = all ranks' rays (a multiple of n_ranks), `workspace`:

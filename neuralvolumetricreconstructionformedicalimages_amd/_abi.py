@@ -108,7 +108,7 @@ SIGNATURES = {
     "naf_render_train_adam": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
                                      ctypes.POINTER(TableAdam), _vp]),
     "naf_levels_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp]),
-    "naf_levels_field_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),
+    "naf_levels_field_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp, _vp]),
     "naf_levels_scatter": (_i32, [_vp, _vp, _vp, ctypes.c_size_t, _u32, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp,
                                   ctypes.POINTER(TableAdam), ctypes.POINTER(ctypes.c_int), _vp]),
     "naf_field_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp]),

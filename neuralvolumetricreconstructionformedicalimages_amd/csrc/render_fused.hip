@@ -1105,7 +1105,8 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
 // launches of ~5 us each were 4 % of the reference-size step); `loss_assign` -- loss_out[0] = loss instead of +=; `deferred` --
 // where to leave the description of the slab reduction instead of launching it (the first scatter_bin launch then runs it in spare
 // workgroups, beside its own: one dependent launch of ~11 us less per step).
-struct StepExtras { uint32_t *clear_words; bool loss_assign; SlabReduce *deferred; };
+struct StepExtras { uint32_t *clear_words; bool loss_assign; SlabReduce *deferred; hipEvent_t after_backward = nullptr; };      // after_backward: recorded once
+                                                                                      // the feature gradients are final, before the slab reduction
 
 static int run_mlp_grad_reduce(const float *slabs, uint32_t n_slabs, float *grad_mlp, float *loss_out, bool with_loss, const MlpAdam *madam,
                                uint32_t *gmax_bits, const StepExtras &ex, hipStream_t s) {
@@ -1139,6 +1140,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
             { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(mlp16_backward_kernel, dim3(grid16), dim3(256), lds16, s, (const uint16_t *)feat, mlp, src,
                                grad_acc, loss, (uint16_t *)dfeat, slabs, n_rays, B, cfg->last_activation, parts, ex.clear_words); }
             if (int rc = check_launch("mlp16_backward_kernel")) return rc;
+            if (ex.after_backward != nullptr && hipEventRecord(ex.after_backward, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp backward: cannot record the event");
             return run_mlp_grad_reduce(slabs, grid16, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
         }
     }
@@ -1149,6 +1151,7 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     { ProfScope prof_("mlp_backward_kernel", s); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const typename P::feat_t::store_t *)feat, mlp, src, grad_acc, loss,
                        (typename P::feat_t::store_t *)dfeat, slabs, n_rays, B, cfg->last_activation, ex.clear_words); }
     if (int rc = check_launch("mlp_backward_kernel")) return rc;
+    if (ex.after_backward != nullptr && hipEventRecord(ex.after_backward, s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "mlp backward: cannot record the event");
     return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
 }
 
@@ -1477,13 +1480,13 @@ static int levels_encode_impl(const float *rays, const float *t_rand, const void
 template <typename P, uint32_t C>
 static int levels_field_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
                              const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                             const naf_render_cfg *cfg, void *ws, hipStream_t s) {
+                             const naf_render_cfg *cfg, void *ws, hipEvent_t grads_ready, hipStream_t s) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
     if (int rc = run_mlp_forward<P, C, true>(features, mlp, src, acc, n_rays, B, cfg, s)) return rc;
     const LossInputs loss{acc, target, ray_weight};
-    const StepExtras ex{nullptr, false, nullptr};
+    const StepExtras ex{nullptr, true, nullptr, grads_ready};
     return run_mlp_backward<P, C>(features, mlp, src, nullptr, loss, feature_grads, w.slabs, nullptr, grad_mlp, loss_out, nullptr, n_rays, B, cfg, ex, s);
 }
 
@@ -1735,16 +1738,19 @@ extern "C" int naf_levels_encode(const float *rays, const float *t_rand, const v
 
 extern "C" int naf_levels_field_step(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *features,
                                      const float *mlp, float *acc, void *feature_grads, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                                     const naf_render_cfg *cfg, void *workspace, void *stream) {
+                                     const naf_render_cfg *cfg, void *workspace, void *grads_ready, void *stream) {
     if (int rc = check_cfg(cfg, "levels_field_step")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
-    if (n_rays == 0) return NAF_OK;
+    if (n_rays == 0) {
+        if (grads_ready != nullptr && hipEventRecord((hipEvent_t)grads_ready, (hipStream_t)stream) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_field_step: event");
+        return NAF_OK;
+    }
     if (!rays || !target || !ray_weight || !features || !mlp || !acc || !feature_grads || !grad_mlp || !loss_out || !workspace)
         return fail(NAF_ERR_INVALID_ARGUMENT, "levels_field_step: null pointer");
     if (cfg->n_samples < 2) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_field_step: n_samples must be >= 2");
     if (int rc = check_points((uint64_t)n_rays * cfg->n_samples)) return rc;
     NAF_DISPATCH_PC(levels_field_impl, rays, t_rand, target, ray_weight, features, mlp, acc, feature_grads, grad_mlp, loss_out, n_rays, cfg,
-                    workspace, (hipStream_t)stream);
+                    workspace, (hipEvent_t)grads_ready, (hipStream_t)stream);
 }
 
 extern "C" int naf_levels_scatter(const float *rays, const float *t_rand, const void *grad_blocks, size_t block_stride_bytes, uint32_t n_ranks,

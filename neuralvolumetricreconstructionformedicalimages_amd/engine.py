@@ -181,6 +181,7 @@ class NAFEngine:
         self._lv = {"levels": (self.rank * per, (self.rank + 1) * per), "per": per,
                     "rows": [(offs[k * per] * C, offs[(k + 1) * per] * C) for k in range(N)],      # element ranges by owner
                     "comm": torch.cuda.Stream(device=self.device), "mlp_ready": event(), "mlp_done": event(), "buf": {},
+                    "grads_ready": event(), "exchange": torch.cuda.Stream(device=self.device),
                     "stale": False, "time": False, "timings": []}
 
     def _all_to_all(self, out, inp):
@@ -247,13 +248,18 @@ class NAFEngine:
         mark()
         self._all_to_all(b["feat"], b["send"])                      # block k of the result = rank k's levels of MY points: [L][points][C]
         mark()
-        self.loss.zero_()
         _abi.check(lib.naf_levels_field_step(_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(b["feat"]),
                                              _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(b["dfeat"]), _abi.ptr(self.mlp_g),
-                                             _abi.ptr(self.loss), n, ctypes.byref(cfg), _abi.ptr(ws), sp), "levels_field_step")
+                                             _abi.ptr(self.loss), n, ctypes.byref(cfg), _abi.ptr(ws), lv["grads_ready"].cuda_event, sp),
+                   "levels_field_step")
         lv["mlp_ready"].record(main)
         mark()
-        self._all_to_all(b["recv"], b["dfeat"])                     # block k = rank k's gradients of MY levels
+        # the gradients' all-to-all starts behind the MLP backward kernel (the event), not behind the slab reduction that follows it
+        ex = lv["exchange"]
+        ex.wait_event(lv["grads_ready"])
+        with torch.cuda.stream(ex):
+            self._all_to_all(b["recv"], b["dfeat"])                 # block k = rank k's gradients of MY levels
+        main.wait_stream(ex)
         mark()
         with torch.cuda.stream(lv["comm"]):                         # issued after the all-to-all, so it queues behind it on the links
             lv["comm"].wait_event(lv["mlp_ready"])

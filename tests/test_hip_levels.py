@@ -51,6 +51,7 @@ def _levels_step(eng, N, rays, target, weight):
                                          ctypes.byref(cfg_all), k * per, (k + 1) * per, sp), "levels_encode")
         feats.append(out)
     eng.loss.zero_()
+    part = torch.zeros(1, device=eng.device)
     acc = torch.empty(n_all, device=eng.device)
     grads = []
     for r in range(N):                                            # "all-to-all": rank r receives every owner's levels of its points
@@ -60,7 +61,8 @@ def _levels_step(eng, N, rays, target, weight):
         sl = slice(r * n, (r + 1) * n)
         _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl].contiguous()), None, _abi.ptr(target[sl].contiguous()), _abi.ptr(weight[sl].contiguous()),
                                              _abi.ptr(feat), _abi.ptr(eng.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(eng.mlp_g),
-                                             _abi.ptr(eng.loss), n, ctypes.byref(cfg), _abi.ptr(ws), sp), "levels_field_step")
+                                             _abi.ptr(part), n, ctypes.byref(cfg), _abi.ptr(ws), None, sp), "levels_field_step")
+        eng.loss.add_(part)                                       # (the all-reduce of the real step)
         grads.append(dfeat)
     eng.step_count += 1
     st = _abi.TableAdam()
@@ -141,6 +143,7 @@ def test_level_parallel_first_step_gradient_matches_the_plain_backward_fp32():
     want = ws_ref[:full.numel() * 4].view(torch.float32).reshape(L, -1)
     assert torch.equal(full, want)
     lev.loss.zero_()
+    part = torch.zeros(1, device=lev.device)
     acc = torch.empty(n_rays, device=lev.device)
     grads = []
     for r in range(N):
@@ -149,7 +152,8 @@ def test_level_parallel_first_step_gradient_matches_the_plain_backward_fp32():
         sl = slice(r * n, (r + 1) * n)
         _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl].contiguous()), None, _abi.ptr(target[sl].contiguous()), _abi.ptr(weight[sl].contiguous()),
                                              _abi.ptr(feat), _abi.ptr(lev.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(lev.mlp_g),
-                                             _abi.ptr(lev.loss), n, ctypes.byref(lev._cfg(r * n)), _abi.ptr(ws), sp), "levels_field_step")
+                                             _abi.ptr(part), n, ctypes.byref(lev._cfg(r * n)), _abi.ptr(ws), None, sp), "levels_field_step")
+        lev.loss.add_(part)
         grads.append(dfeat)
     for k in range(N):
         blocks = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0).contiguous()
