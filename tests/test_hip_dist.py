@@ -272,7 +272,8 @@ def test_bench_two_rank_launch_rehearsal(rays):
     assert "cpu_baseline" not in out                               # rank 0 at N = 1 only
 
 
-def test_train_py_under_torchrun_equals_the_single_process_run(tmp_path):
+@pytest.mark.parametrize("table_dtype,dp_mode", [("float32", "sharded"), ("bfloat16", "sharded"), ("bfloat16", "levels")])
+def test_train_py_under_torchrun_equals_the_single_process_run(tmp_path, table_dtype, dp_mode):
     """`python -m torch.distributed.run --nproc-per-node 2 train.py --config ...` (the documented data-parallel launch;
     here the two ranks share the one GPU of the test box and talk through gloo: NAF_DIST_BACKEND / NAF_DIST_SHARE_GPU)
     trains to the same parameters as `python train.py --config ...` on the same seeded pixel draws: the ranks take slices of
@@ -298,7 +299,7 @@ def test_train_py_under_torchrun_equals_the_single_process_run(tmp_path):
             "render": {"n_samples": 32, "n_fine": 0, "perturb": True, "raw_noise_std": 0.0, "netchunk": 4096},
             "train": {"epoch": 2, "n_batch": 1, "n_rays": 256, "lrate": 5e-3, "lrate_gamma": 0.5, "lrate_step": 1, "resume": False},
             "log": {"i_eval": 2, "i_save": 2},
-            "backend": {"engine": "fused", "table_dtype": "float32", "loss": "global_mean", "seed": 3},
+            "backend": {"engine": "fused", "table_dtype": table_dtype, "loss": "global_mean", "seed": 3, "dp_mode": dp_mode},
         }
         path = tmp_path / f"{name}.yaml"
         path.write_text(yaml.safe_dump(cfg))
@@ -322,6 +323,14 @@ def test_train_py_under_torchrun_equals_the_single_process_run(tmp_path):
     assert a["epoch"] == b["epoch"] == 2
     for key in b["network"]:
         x, y = a["network"][key].float().cpu(), b["network"][key].float().cpu()
-        assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-3), key
+        if table_dtype == "float32":
+            assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-3), key
+        else:      # bf16 records: sums differ in their last bits, Adam turns a near-zero gradient into a step of +-lr on a few rows
+            assert float(((x - y).abs() > 1e-2 * max(float(y.abs().max()), 1e-3)).float().mean()) < 1e-2, key
+    # the checkpoint holds the COMPLETE optimiser state and fp32 master table although every rank steps only its shard / its levels
+    # (Trainer gathers them before it evaluates and before it saves)
+    ma, mb = a["optimizer"]["state"][0]["exp_avg"].float().cpu(), b["optimizer"]["state"][0]["exp_avg"].float().cpu()
+    tol = (1e-4 if table_dtype == "float32" else 3e-2) * float(mb.abs().max())
+    assert float(((ma - mb).abs() > tol).float().mean()) < 1e-2
     assert os.path.exists(tmp_path / "dp" / "eval" / "epoch_00002" / "stats.txt")
     assert dp.stdout.count("[SAVE]") == 1                                  # rank 0 only
