@@ -187,3 +187,66 @@ def test_sharded_optimizer_exchange_equals_all_reduce_then_adam():
             assert abs(share - 1.0 / world) < 0.01                   # every rank steps 1/N of the table
             assert ranges[-1][0] == 0 and max(b for _, b in ranges) == n_pad
             assert all((b - a) % (4 * world) == 0 and a % 4 == 0 for a, b in ranges)
+
+
+# ---- level-parallel exchange (engine._train_step_levels): the two all-to-alls, on CPU --------------------------------------------
+def _levels_worker(rank, world, port, q):
+    """A per-level linear 'encoder' stands in for the hash grid: feature(l, point) = table[l] * x(point).  Rank k owns L / world
+    levels; the features of its levels for every rank's points go out in one block per destination, the gradients come back the
+    same way -- the buffer layouts of naf_levels_encode / naf_levels_field_step / naf_levels_scatter."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    _, _, _, group = dist.init_from_env(device_type="cpu")
+    L, run = 8, 5                                   # levels, points x C of one rank
+    per = L // world
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(L, generator=g)             # every rank knows the whole table here; it READS only the levels it owns
+    x_all = torch.randn(world, run, generator=g)    # rank r's points
+    head = torch.randn(L, generator=g)              # the 'MLP': acc = sum_l head[l] * feature[l]
+    lb = rank * per
+    send = torch.stack([torch.stack([table[lb + l] * x_all[r] for l in range(per)]) for r in range(world)])      # [dest][owned level][run]
+    feat = torch.empty(L, run)
+    td.all_to_all_single(feat.view(-1), send.view(-1), group=group)          # block k = rank k's levels of MY points -> [L][run]
+    want = table[:, None] * x_all[rank][None, :]
+    assert torch.equal(feat, want)
+    dfeat = head[:, None] * torch.ones(L, run) * (rank + 1)                  # d loss / d feature of my points, [L][run]
+    recv = torch.empty(world, per * run)
+    td.all_to_all_single(recv.view(-1), dfeat.view(-1), group=group)         # block k = rank k's gradients of MY levels
+    grad_owned = torch.stack([sum(recv[r].view(per, run)[l] @ x_all[r] for r in range(world)) for l in range(per)])
+    q.put((rank, grad_owned.numpy()))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_level_parallel_exchange_layout_gives_the_single_process_table_gradient():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 77) % 2000)
+    procs = [ctx.Process(target=_levels_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(collect(procs, q, len(procs), timeout=120), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L, run = 8, 5
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(L, generator=g).requires_grad_(True)
+    x_all = torch.randn(world, run, generator=g)
+    head = torch.randn(L, generator=g)
+    loss = sum((r + 1) * (head[:, None] * (table[:, None] * x_all[r][None, :])).sum() for r in range(world))
+    loss.backward()
+    got = np.concatenate([r[1] for r in results])
+    np.testing.assert_allclose(got, table.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_pick_dp_mode_by_bytes_on_the_links():
+    chest = dict(num_levels=16, level_dim=2, table_elements=14262438)
+    assert dist.pick_dp_mode(1, points_per_step=1024 * 192, **chest) == "sharded"             # nothing to exchange
+    assert dist.pick_dp_mode(8, points_per_step=1024 * 192, **chest) == "levels"              # 25 MB against 85.5 MB
+    assert dist.pick_dp_mode(8, points_per_step=3072 * 192, **chest) == "levels"
+    assert dist.pick_dp_mode(8, points_per_step=4096 * 192, **chest) == "sharded"             # 100 MB against 85.5 MB
+    assert dist.pick_dp_mode(8, points_per_step=65536 * 192, **chest) == "sharded"
+    assert dist.pick_dp_mode(3, points_per_step=1024 * 192, **chest) == "sharded"             # 16 levels do not split three ways
+    assert dist.pick_dp_mode(8, points_per_step=None, **chest) == "sharded"                   # unknown batch: the safe choice
+    assert dist.pick_dp_mode(8, points_per_step=2048 * 192, feature_bytes=4, table_bytes=4, **chest) == "levels"      # fp32: 100 MB against 114 MB
