@@ -204,6 +204,11 @@ typedef struct naf_render_cfg {
                                             slice of the table is pulled through four L2s instead of eight (encode_kernel); without a
                                             flag the batch size decides: 4 groups below 160 000 points per call, 2 below 500 000    */
 #define NAF_CFG_ENCODE_GROUPS_4 1024u    /* ... into 4 groups (levels mod 4); both flags: 8 groups, one level per XCD at a time       */
+#define NAF_CFG_MIN_BUCKETS_SHIFT 13u    /* bits 13-14: the binned scatter uses at least 64 << value row buckets per level (default: as few as the
+                                            reducer's LDS allows, 64 at T = 2^19).  A level-parallel rank that owns two or four levels asks
+                                            for 256 / 128, so that its reducer launch has 512 workgroups that each own their rows (no split
+                                            launches, the Adam tail applies) -- naf_levels_scatter                                        */
+#define NAF_CFG_MIN_BUCKETS_MASK (3u << NAF_CFG_MIN_BUCKETS_SHIFT)
 #define NAF_CFG_TEST_TINY_BLOCKS 4096u   /* tests: the record blocks of pass 1 hold a quarter of a tile's records, so that most
                                             records take the overflow route (counted global atomics) and the reducer's Adam tail has
                                             spilled contributions to fold in                                                        */

@@ -823,6 +823,10 @@ static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan 
     const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
     uint32_t log2_nb = 6;
     while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
+    // NAF_CFG_MIN_BUCKETS: more, smaller buckets on request (a bucket keeps at least 64 rows)
+    const uint32_t want_nb = 6u + ((cfg->flags & NAF_CFG_MIN_BUCKETS_MASK) >> NAF_CFG_MIN_BUCKETS_SHIFT);
+    const uint32_t cap_nb = cfg->log2_hashmap_size >= 12u ? cfg->log2_hashmap_size - 6u : 6u;
+    log2_nb = std::max(log2_nb, std::min(want_nb, cap_nb));
     const size_t rec = record_bytes(cfg);
     // Tables of 2^20 rows per level and more need 128 .. 512 buckets (the reducer's rows must fit the LDS), which cuts a
     // 1024-point tile into runs of 8 .. 32 records -- short, ragged reads in pass 2.  With 12-byte records a 2048-point
@@ -887,7 +891,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;

@@ -102,6 +102,7 @@ class NAFEngine:
         # Each extra stream owns a gradient buffer, a workspace and a loss cell; they are summed before Adam.
         self._dp = None
         self._lv = None
+        self._levels_flags = 0
         if process_group is not None:
             if int(n_streams) > 1:
                 raise ValueError("NAFEngine: n_streams > 1 cannot be combined with a process group (the bucket events are "
@@ -171,6 +172,10 @@ class NAFEngine:
         if L % N != 0:
             raise ValueError(f"dp_mode 'levels' needs a world size that divides the {L} levels (got {N}); use 'sharded'")
         per = L // N
+        # with one or two levels per rank the scatter uses 256 row buckets per level instead of 64 (NAF_CFG_MIN_BUCKETS): 256 / 512 reducer
+        # workgroups that each own their rows, so that no launch is split and the reducer applies Adam itself (tools/levels_emulate.py,
+        # 8 ranks: reduce + Adam 0.102 -> 0.064 ms per step; with four levels per rank 128 buckets measured no gain: 0.270 against 0.261 ms)
+        self._levels_flags = {1: 2, 2: 2}.get(per, 0) << _abi.CFG_MIN_BUCKETS_SHIFT
         offs = [int(v) for v in self.offsets.tolist()]
         C = self.net.encoder.level_dim
 
@@ -308,7 +313,7 @@ class NAFEngine:
                               seed=(self.seed + 0x9E3779B97F4A7C15 * (self.step_count + 1)) & (2 ** 64 - 1),
                               ray_index_base=int(ray_base), log2_hashmap_size=int(enc.log2_hashmap_size),
                               scatter_mode=fused._default_scatter_mode if self.scatter_mode is None else int(self.scatter_mode),
-                              flags=fused._default_flags if self.cfg_flags is None else int(self.cfg_flags))
+                              flags=(fused._default_flags if self.cfg_flags is None else int(self.cfg_flags)) | self._levels_flags)
 
     @property
     def table(self):

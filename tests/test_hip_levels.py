@@ -86,13 +86,19 @@ def _levels_step(eng, N, rays, target, weight):
     return acc, fused_tail
 
 
-@pytest.mark.parametrize("N,table,n_rays,S,expect_fused", [(2, "fp32", 256, 64, True), (2, "bf16", 256, 64, True), (8, "bf16", 512, 64, False),
-                                                             (8, "fp32", 256, 48, False), (4, "bf16", 16, 32, False)])
-def test_level_parallel_entry_points_equal_the_single_gpu_step(N, table, n_rays, S, expect_fused):
+@pytest.mark.parametrize("N,table,n_rays,S,buckets,expect_fused", [
+    (2, "fp32", 256, 64, 0, True), (2, "bf16", 256, 64, 0, True),
+    (8, "bf16", 512, 64, 0, False), (8, "fp32", 256, 48, 0, False),      # two levels per rank, 64 row buckets: split reducer launches, separate Adam pass
+    (8, "bf16", 512, 64, 2, True), (8, "fp32", 256, 48, 2, True),        # ... 256 row buckets (NAF_CFG_MIN_BUCKETS, what the engine asks for): the Adam tail applies
+    (4, "bf16", 512, 64, 1, True),
+    (4, "bf16", 16, 32, 0, False)])                                      # 512 points: the atomic scatter
+def test_level_parallel_entry_points_equal_the_single_gpu_step(N, table, n_rays, S, buckets, expect_fused):
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi
     from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
     dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[table]
     ref = NAFEngine(_make(), S, perturb=True, lr=1e-2, table_dtype=dtype, seed=5)
     lev = NAFEngine(_make(), S, perturb=True, lr=1e-2, table_dtype=dtype, seed=5)
+    lev._levels_flags = buckets << _abi.CFG_MIN_BUCKETS_SHIFT
     rays, target, mask = _batch(n_rays, S)
     weight = mask.float() / mask.float().sum()
     for step in range(2):

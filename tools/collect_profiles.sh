@@ -59,6 +59,15 @@ for a in "--log2T 22 --samples 320 --table fp16 --rays 32768" "--log2T 21 --samp
   timeout -k 10 100 python tools/step_bench.py $a 2>> $OUT/shapes.err | tail -n 1 >> $OUT/shapes.jsonl
 done
 echo eval + shapes done
+# level-parallel step at chest size, N virtual ranks in one process: parity with the single-GPU step and one rank's share of the kernels
+rm -f $OUT/levels_emulation.jsonl
+for n in 2 4 8; do
+  timeout -k 10 200 python tools/levels_emulate.py --ranks $n 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+done
+timeout -k 10 200 python tools/levels_emulate.py --ranks 8 --default-buckets 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+timeout -k 10 200 python tools/levels_emulate.py --ranks 8 --precision fp32 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+timeout -k 10 200 python bench.py --force-dp --dp-mode levels --steps 1000 --psnr-seconds 0 --cpu-seconds 0 --sub-records 0 2> $OUT/levels_one_rank.err | tail -n 1 > $OUT/bench_level_parallel_one_rank.json
+echo level-parallel emulation done
 # T = 2^22 (foot_50 shapes, the table is larger than every cache level below the Infinity Cache): HBM bytes fetched by the
 # encoder of the FUSED forward, quoted against the north star's 60 % bar in DESIGN.md section 4.1
 for t in fp16 fp32; do

@@ -35,6 +35,7 @@ copy("bench_fp32_16384.json", f"{TAG}_bench_fp32_16384rays.json")
 copy("bench_per_level_16384.json", f"{TAG}_bench_per_level_16384rays.json")
 for src, dst in (("bench_force_dp.json", "bench_data_parallel_step_one_gpu.json"), ("bench_interleaved.json", "bench_levels_interleaved_encoder.json"), ("eval.jsonl", "eval_throughput.jsonl"),
                  ("train_py.json", "train_py_throughput.json"), ("shapes.jsonl", "other_shapes_step_times.jsonl"),
+                 ("levels_emulation.jsonl", "level_parallel_emulation.jsonl"), ("bench_level_parallel_one_rank.json", "bench_level_parallel_one_rank.json"),
                  ("psnr_16384_bf16.json", "chest_psnr_vs_time_16384rays.json"), ("psnr_16384_fp32.json", "chest_psnr_vs_time_16384rays_fp32.json"),
                  ("psnr_1024_bf16.json", "chest_psnr_vs_time_1024rays.json"), ("psnr_race_grid.jsonl", "psnr_race_grid.jsonl")):
     if os.path.exists(os.path.join(SRC, src)):
