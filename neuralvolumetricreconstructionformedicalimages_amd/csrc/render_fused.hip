@@ -1438,17 +1438,26 @@ levels_gather_kernel(const unsigned char *__restrict__ blocks, size_t block_stri
     const T *src = reinterpret_cast<const T *>(blocks + (size_t)r * block_stride) + (size_t)l * run;
     T *out = dst + ((size_t)(lv_begin + l) * n_ranks + r) * run;
     uint32_t m = 0u;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x) {
-        if constexpr (kVec) {
-            const uint4 q = reinterpret_cast<const uint4 *>(src)[u];
-            reinterpret_cast<uint4 *>(out)[u] = q;
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    const uint32_t stride = gridDim.x * blockDim.x;
+    if constexpr (kVec) {
+        constexpr uint32_t kFlight = 4u;                            // 16-byte loads in flight per lane
+        for (uint32_t u0 = blockIdx.x * blockDim.x + threadIdx.x; u0 < units; u0 += kFlight * stride) {
+            uint4 q[kFlight];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if constexpr (sizeof(T) == 2) m = max(m, max(abs_bits<uint16_t>((uint16_t)(w[k] & 0xffffu)), abs_bits<uint16_t>((uint16_t)(w[k] >> 16))));
-                else m = max(m, abs_bits<uint32_t>(w[k]));
+            for (uint32_t j = 0; j < kFlight; ++j) q[j] = reinterpret_cast<const uint4 *>(src)[min(u0 + j * stride, units - 1u)];
+#pragma unroll
+            for (uint32_t j = 0; j < kFlight; ++j) {
+                if (u0 + j * stride < units) reinterpret_cast<uint4 *>(out)[u0 + j * stride] = q[j];
+                const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if constexpr (sizeof(T) == 2) m = max(m, max(abs_bits<uint16_t>((uint16_t)(w[k] & 0xffffu)), abs_bits<uint16_t>((uint16_t)(w[k] >> 16))));
+                    else m = max(m, abs_bits<uint32_t>(w[k]));
+                }
             }
-        } else {
+        }
+    } else {
+        for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
             const T v = src[u];
             out[u] = v;
             m = max(m, abs_bits<T>(v));
@@ -1510,8 +1519,8 @@ static int levels_scatter_impl(const float *rays, const float *t_rand, const voi
     const bool vec = (run * sizeof(T)) % 16u == 0u && block_stride % 16u == 0u && ((uintptr_t)blocks & 15u) == 0u && ((uintptr_t)w.dfeat & 15u) == 0u;
     if ((uint64_t)n_ranks * nl > 65535u) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: too many (rank, level) blocks");
     const uint32_t units = vec ? run / (uint32_t)(16u / sizeof(T)) : run;
-    // ~2 048 workgroups in all, each lane moving a few 16-byte pieces
-    const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((units + 1023u) / 1024u, std::max<uint32_t>(1u, 2048u / (n_ranks * nl))));
+    // ~512 workgroups in all: each ends with ONE atomic on the same word, and same-address atomics retire ~12 ns apart
+    const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((units + 1023u) / 1024u, std::max<uint32_t>(1u, 512u / (n_ranks * nl))));
     {
         ProfScope prof_("levels_gather_kernel", s);
         if (vec) hipLaunchKernelGGL((levels_gather_kernel<T, true>), dim3(gx, n_ranks * nl), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);

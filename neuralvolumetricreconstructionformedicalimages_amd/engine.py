@@ -270,8 +270,9 @@ class NAFEngine:
             lv["comm"].wait_event(lv["mlp_ready"])
             o_mlp = self._emb_flat.numel()
             dist.all_reduce(self.grad_flat[o_mlp:], group=grp)      # MLP gradient + loss
+            self.step_count += 1
+            self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")      # beside the scatter, not behind it
             lv["mlp_done"].record(lv["comm"])
-        self.step_count += 1
         b1, b2 = self.betas
         st = _abi.TableAdam()
         st.param, st.exp_avg, st.exp_avg_sq = self.emb.data_ptr(), self.emb_m.data_ptr(), self.emb_v.data_ptr()
@@ -286,8 +287,7 @@ class NAFEngine:
             # the reducer launches were split (few levels per rank) or the batch took the atomic scatter: the gradient of the owned
             # rows sits in emb_g
             self._adam_rows(*lv["rows"][r], what="adam_step(owned levels)")
-        main.wait_event(lv["mlp_done"])
-        self._adam(self.mlp, self.mlp_m, self.mlp_v, self.mlp_g, None, 0, "adam_step(mlp)")
+        main.wait_event(lv["mlp_done"])                              # the next step reads the stepped MLP
         mark()
         if lv["time"]:
             lv["timings"].append(marks)
