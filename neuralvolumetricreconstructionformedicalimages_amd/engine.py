@@ -332,6 +332,9 @@ class NAFEngine:
 
     def backward(self, rays, target, weight, t_rand=None, ray_base=0):
         """Forward + weighted squared error + backward: fills the gradient buffers, returns acc [n]."""
+        if self._lv is not None:
+            raise NotImplementedError("dp_mode 'levels' has no separate backward / optimizer_step: a rank holds only its levels' rows "
+                                      "(use train_step)")
         n = rays.shape[0]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
