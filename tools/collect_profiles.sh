@@ -66,6 +66,9 @@ for n in 2 4 8; do
 done
 timeout -k 10 200 python tools/levels_emulate.py --ranks 8 --default-buckets 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
 timeout -k 10 200 python tools/levels_emulate.py --ranks 8 --precision fp32 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+for r in 1024 4096; do      # foot_50 shapes
+  timeout -k 10 300 python tools/levels_emulate.py --ranks 8 --rays $r --log2T 22 --samples 320 --table fp16 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+done
 timeout -k 10 200 python bench.py --force-dp --dp-mode levels --steps 1000 --psnr-seconds 0 --cpu-seconds 0 --sub-records 0 2> $OUT/levels_one_rank.err | tail -n 1 > $OUT/bench_level_parallel_one_rank.json
 echo level-parallel emulation done
 # T = 2^22 (foot_50 shapes, the table is larger than every cache level below the Infinity Cache): HBM bytes fetched by the
