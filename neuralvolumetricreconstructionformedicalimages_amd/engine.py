@@ -217,6 +217,14 @@ class NAFEngine:
         if n == 0:
             raise ValueError("dp_mode 'levels': every rank needs the same, non-zero number of rays per step")
         main = torch.cuda.current_stream(self.device)
+        if lv.get("checked_n") != n:
+            # a new batch size: every rank must bring the same number of rays (the collectives use equal splits) -- checked once per size
+            both = torch.tensor([n, -n], device=self.device, dtype=torch.int64)
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=grp)
+            if int(both[0]) != n or int(both[1]) != -n:
+                raise ValueError(f"dp_mode 'levels': ranks hold different numbers of rays this step (this rank {n}, largest {int(both[0])}, "
+                                 f"smallest {-int(both[1])}); use dp_mode 'sharded' for uneven shards")
+            lv["checked_n"] = n
         if rays_all is None:
             rays_all = torch.empty(N * n, 8, device=self.device)
             dist.all_gather_into_tensor(rays_all, rays.contiguous(), group=grp)

@@ -138,7 +138,8 @@ class Trainer:
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
                                     table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group,
-                                    dp_mode=backend.get("dp_mode", "auto"),      # levels / sharded by the bytes on the links (dist.pick_dp_mode)
+                                    # levels / sharded by the bytes on the links (dist.pick_dp_mode); level-parallel ranks need equal shards
+                                    dp_mode=backend.get("dp_mode", "auto" if self._even_shards else "sharded"),
                                     rays_per_step_hint=-(-int(cfg["train"]["n_rays"]) // max(self.world, 1)))
             self.engine.broadcast_parameters()
             self.optimizer = _EngineOptimizer(self.engine)
