@@ -380,7 +380,14 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
             const uint32_t n_chunk = min(((n_rec * (uint32_t)sizeof(Rec) + 127u) >> 7) << 3, (SLOTS * (uint32_t)sizeof(Rec)) >> 4);
             uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(blocks + block_index(plan, ly, tile));
             const uint4 *from = reinterpret_cast<const uint4 *>(staging);
-            for (uint32_t c = threadIdx.x; c < n_chunk; c += NT) dst[c] = from[c];
+            // Non-temporal stores: the records are written once and read once by pass 2, and at the reference's batch they (151 MB)
+            // and the optimiser state pass 2 streams (171 MB of fp32 master + moments, every step) do not both fit the 256 MB
+            // Infinity Cache -- kept out of it, they leave the state there.  Same-box A/B, 1 024 rays: step 0.311 -> 0.301 ms (pass 1
+            // 0.056 -> 0.053, pass 2 0.114 -> 0.109); flat from 16 384 rays on.  (The same hint on the feature-gradient and feature
+            // stores helps their writers at large batches and costs their readers more at this one, and non-temporal record LOADS in pass 2
+            // cost it 2-4 %: not used.)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            for (uint32_t c = threadIdx.x; c < n_chunk; c += NT) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(from)[c], reinterpret_cast<u32x4 *>(dst) + c);
         }
         if (__ballot(n_overflow_level != 0u)) {                          // diagnostics: overflow per level (overflow[1 + level])
 #pragma unroll
