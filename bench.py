@@ -258,16 +258,74 @@ def psnr_race(scan, n_rays, lr, precision="bf16", thresholds=(30.0, 35.0, 38.0),
     keep = curve[::max(1, len(curve) // 24)]
     if keep[-1] is not curve[-1]:
         keep.append(curve[-1])
+    # `time_to_psnr` is the HELD figure (a first crossing is a lucky peak of a curve that oscillates by +-1.5 dB);
+    # the first crossings stay in the record under their own name.
     return {"rays_per_step": n_rays, "lr": lr, "precision": precision, "loss": loss_name, "burst_steps": burst,
-            "time_to_psnr": reached, "held_from": held, "final": curve[-1], "train_seconds": round(t_train, 4), "steps": steps,
+            "time_to_psnr": held, "first_crossing": reached, "final": curve[-1], "train_seconds": round(t_train, 4), "steps": steps,
             "sustained_rays_per_s": steps * n_rays / t_train, "ms_per_step": round(t_train / steps * 1e3, 4), "curve": keep}
 
 
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` with no torchrun environment: start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD process (never exec: this process may not replace itself once anything has touched the GPU, and nothing here has),
+    let rank 0's JSON line through on the inherited stdout and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, cwd=REPO)
+
+
+def full_schedule(scan, precision, seed=0, epochs=None, eval_epochs=25, thresholds=(30.0, 35.0, 38.0), log=None):
+    """The PSNR half of the metric on the reference's OWN schedule (config/chest_50.yaml:27-33 + src/trainer.py:54-58,83-132): `epoch`
+    epochs of one 1 024-ray step per projection (50 x 1 500 = 75 000 steps, 76.8 M rays), Adam at `lrate` with StepLR(lrate_step,
+    lrate_gamma) stepped once per epoch, loss = sum of 200-ray chunk means -- from scratch, in the given precision.  Pixel draws
+    (sampler seed, step) and jitter (engine seed, ray index) do not depend on the precision, so a bf16 and an fp32 run see identical
+    data.  Returns the final reconstructed-volume PSNR, the training seconds (evaluation excluded) and the PSNR curve."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(REPO, "config", "chest_50.yaml")))["train"]
+    n_rays, lr0, gamma, lr_step = int(cfg["n_rays"]), float(cfg["lrate"]), float(cfg["lrate_gamma"]), int(cfg["lrate_step"])
+    epochs = int(cfg["epoch"]) if epochs is None else int(epochs)
+    per_epoch = scan.raygen.n_projections                          # len(train_dloader): one item per projection, n_batch = 1
+    device = scan.device
+    rays = torch.empty(n_rays, 8, device=device)
+    weight, loss_name = step_weights(n_rays, device)
+    engine = make_chest_engine(device, precision, lr0, seed=seed)
+    curve = [{"train_s": 0.0, "epoch": 0, "steps": 0, "psnr_db": round(scan.volume_psnr(engine.net), 3)}]
+    t_train, step = 0.0, 0
+    for e0 in range(0, epochs, eval_epochs):
+        e1 = min(epochs, e0 + eval_epochs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in range(e0, e1):
+            engine.lr = lr0 * gamma ** (e // lr_step)              # StepLR: the scheduler steps at the END of every epoch (trainer.py:130)
+            for _ in range(per_epoch):
+                target, _r = scan.sampler.draw(step, n_rays, rays)
+                engine.train_step(rays, target, weight, ray_base=step * n_rays)
+                step += 1
+        torch.cuda.synchronize()
+        t_train += time.perf_counter() - t0
+        curve.append({"train_s": round(t_train, 3), "epoch": e1, "steps": step, "psnr_db": round(scan.volume_psnr(engine.net), 3)})
+        if log is not None and (e1 % 250 == 0 or e1 == epochs):
+            log(f"  full schedule {precision}: epoch {e1}/{epochs}, {t_train:.1f} s of training, {curve[-1]['psnr_db']:.2f} dB")
+    held = {}
+    for th in thresholds:                                           # training time from which the PSNR stayed at or above the threshold
+        below = [i for i, c in enumerate(curve) if c["psnr_db"] < th]
+        k = (below[-1] + 1) if below else 0
+        held[f"{th:g}dB"] = None if k >= len(curve) else {"train_s": curve[k]["train_s"], "steps": curve[k]["steps"]}
+    tail = [c["psnr_db"] for c in curve[-8:]]
+    return {"precision": precision, "epochs": epochs, "steps": step, "rays": step * n_rays, "rays_per_step": n_rays, "lr": lr0,
+            "lr_schedule": f"StepLR(step_size={lr_step} epochs, gamma={gamma:g})", "loss": loss_name,
+            "psnr_db": curve[-1]["psnr_db"], "psnr_db_last_8_evals_min_max": [min(tail), max(tail)],
+            "train_seconds": round(t_train, 3), "rays_per_s": step * n_rays / t_train, "time_to_psnr": held,
+            "curve": curve[::max(1, len(curve) // 30)] + ([curve[-1]] if (len(curve) - 1) % max(1, len(curve) // 30) else [])}
+
+
 def main():
-    # ONE JSON line on stdout: libraries that print to file descriptor 1 (RCCL's version banner at the first collective) are
-    # sent to stderr for the whole run; the result line is written to the real stdout at the end.
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 0.6 s of back-to-back steps at the reference's batch size (a 20-step region is 6 ms: clocks and caches have not settled)
@@ -282,6 +340,10 @@ def main():
     ap.add_argument("--lr", type=float, default=None, help="Adam learning rate (default: chest_50.yaml's 1e-3)")
     ap.add_argument("--psnr-seconds", type=float, default=12.0,
                     help="training-time budget of each PSNR race (time to 30 / 35 / 38 dB volume PSNR; N = 1 only; 0 disables)")
+    ap.add_argument("--full-schedule", type=int, default=1,
+                    help="1: train chest_50.yaml's own schedule (1 500 epochs x 50 steps of 1 024 rays) from scratch in bf16 AND in the fp32 "
+                         "parity mode on identical draws and report both final volume PSNRs (N = 1 only; ~60 s); 0 disables")
+    ap.add_argument("--full-schedule-epochs", type=int, default=None, help="diagnostics: shorten the full schedule")
     ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
                     help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_render_cfg.scatter_mode)")
     ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
@@ -299,21 +361,26 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostics on one GPU: run the data-parallel step (bucketed scatter, RCCL collectives on the side "
                          "stream, per-bucket Adam) with a world-size-1 process group")
-    ap.add_argument("--dp-mode", choices=["auto", "levels", "sharded", "allreduce"], default="auto",
+    ap.add_argument("--dp-mode", choices=["auto", "levels", "sharded", "allreduce"], default="sharded",
                     help="N > 1: levels = each rank owns L/N levels, two all-to-alls of features / feature gradients per step; sharded = "
                          "reduce-scatter of the table gradient -> per-rank Adam on a table slice -> all-gather; allreduce = all-reduce + "
-                         "replicated Adam; auto (default) = whichever puts fewer bytes on the links (levels below ~3 300 rays per GPU)")
+                         "replicated Adam; auto = whichever puts fewer bytes on the links (levels below ~3 300 rays per GPU).  Default sharded: the "
+                         "level-parallel step stays opt-in until it has run over RCCL on more than one rank (DESIGN.md section 6)")
     ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,0-8 (default: dist.default_bucket_levels -- one range below 2^20 points per step)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:                # bare `python bench.py --gpus N`: become the launcher
+        raise SystemExit(launch_ranks(args.gpus))
+    # ONE JSON line on stdout: libraries that print to file descriptor 1 (RCCL's version banner at the first collective) are
+    # sent to stderr for the whole run; the result line is written to the real stdout at the end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
@@ -435,6 +502,9 @@ def main():
     engine.comm_timing(False)
     n_scatter = n * world if levels_mode else n               # a level-parallel rank scatters every rank's points (its levels)
     overflow = engine.scatter_overflow(n_scatter)
+    overflow_levels = engine.scatter_overflow_levels(n_scatter)     # read HERE: the sub-records below re-lay the workspace out
+    if overflow_levels is not None and overflow is not None and sum(overflow_levels) != overflow:
+        raise SystemExit(f"scatter overflow counters disagree: total {overflow}, per level {overflow_levels}")
 
     def timed(fn, steps, warm):
         for i in range(warm):
@@ -484,6 +554,16 @@ def main():
             log(f"PSNR race {name}: {m} rays/step, lr {lr}")
             psnr[name] = psnr_race(scan, m, lr, args.precision, max_train_s=args.psnr_seconds)
             log(f"  -> {psnr[name]['time_to_psnr']}")
+
+    # ---- ... and the same half on the reference's own schedule, in both precisions ------------------------------------------------
+    schedule = None
+    if rank == 0 and world == 1 and args.full_schedule and not args.force_dp:
+        schedule = {}
+        for prec in ("bf16", "fp32"):
+            log(f"full schedule ({prec}): chest_50.yaml's epochs x projections x 1024 rays, from scratch")
+            schedule[prec] = full_schedule(scan, prec, seed=args.seed, epochs=args.full_schedule_epochs, log=log)
+            torch.cuda.empty_cache()
+        schedule["psnr_db_abs_difference"] = round(abs(schedule["bf16"]["psnr_db"] - schedule["fp32"]["psnr_db"]), 3)
 
     if rank == 0:
         rays_total = world * n * args.steps
@@ -563,8 +643,8 @@ def main():
                                    + ("; the operating point that reaches 35 dB volume PSNR soonest (psnr.*, profiles/round3_psnr_race_grid.jsonl)"
                                       if n == CHEST["yaml_rays"] else ""),
                        "rays_per_step_per_gpu": n, "n_samples": CHEST["n_samples"], "lr": engine.lr, "parallelism": (f"lp{world}" if levels_mode else f"dp{world}")},
-            "final_loss": final_loss, "sustained": sustained, "psnr": psnr,
-            "scatter_overflow_last_step": overflow, "scatter_overflow_levels": engine.scatter_overflow_levels(n_scatter),
+            "final_loss": final_loss, "sustained": sustained, "psnr": psnr, "full_schedule": schedule,
+            "scatter_overflow_last_step": overflow, "scatter_overflow_levels": overflow_levels,
             "library_kernels_ms_per_step": round(kernel_ms, 4),
             "profiled_pass": {"steps": prof_steps, "ms_per_step": round(prof_elapsed / prof_steps * 1e3, 4),
                               "note": "per-kernel HIP-event pairs switched on; not the timed region"},
@@ -592,6 +672,12 @@ def main():
                 out["allreduce_exposed_ms_per_step"] = round(max(0.0, comm["tail_ms_per_step"] - per_step.get("adam_kernel", 0.0)), 4)
         if sub_records is not None:
             out["sub_records"] = sub_records
+            par = sub_records.get(f"fp32_parity_mode_{CHEST['yaml_rays']}_rays")
+            if par is not None:
+                # the mode that meets BOTH parity bars of the north star (projection rel. L2 1e-4 and PSNR +-0.1 dB): the reference's own
+                # arithmetic (fp32 table, fp32 MFMA = an fmaf chain, fp32 scatter records), same YAML step, same box, same run
+                out["parity_mode"] = {"value": par["rays_per_s"], "unit": "rays/s", "ms_per_step": par["ms_per_step"], "dtype": "f32",
+                                      "rays_per_step": par["rays_per_step"], "loss": par["loss"]}
         if world == 1 and args.cpu_seconds > 0 and not args.force_dp:
             log("cpu_baseline leg (oracle, host cores)")
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)

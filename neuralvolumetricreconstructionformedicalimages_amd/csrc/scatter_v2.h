@@ -1,0 +1,335 @@
+// scatter_v2.h -- the binned hash-table gradient scatter for the canonical NAF shape (two bf16 channels), on an instruction diet
+// (round 4).  Same two passes as scatter_binned.h (exact per-tile multisplit -> per-bucket reduction in 64-bit fixed point,
+// hashencoder.cu:201-272 is what both replace) and the same workspace layout (BinPlan: blocks [level][tile][slots], run words
+// [level][bucket][tile]); what changed is what a record is and how little arithmetic each one costs.  Counter evidence that asked for
+// it (profiles/round3_sq_counters.md, round3_wave_state.md): pass 1 spent 283 vector instructions per point and level and two LDS
+// atomics per record, pass 2 ran its vector pipe 54 % busy converting through fp64.
+//
+// RECORD (8 bytes instead of 12).  The x-neighbour corners of a cell take w_x = 1 - f_x and f_x of the same product g * w_y * w_z, so
+// a record carries that product ONCE and the fraction next to the row:
+//     head = local row of the first corner (13 bits) | e << 13 (4 bits) | f_x << 17 (15-bit fixed point)
+//     pay  = 2 x bf16:  g[c] * (w_y * w_z)
+// and the reducer forms pay * (1 - f_x) for the row `local` and pay * f_x for the row `local ^ (2^e - 1)`.  (bf16 x 15 bits = 23 bits:
+// both products and the difference are EXACT in fp32, so the only roundings are the bf16 payload and the fixed-point conversion.)
+// e = 0 marks a SINGLE record (f_x = 0: the whole payload goes to `local`); it is used where the two corners have different owners
+// and on the coarse levels whose equal-cell runs are merged inside the wave (the merged sums of the two corners are not one
+// product times one fraction any more).  512 instead of 768 bytes per point and pass through HBM, ds_write_b64 instead of
+// ds_write_b96 into the staging block.
+//
+// BUCKET = the TOP bits of the row: bucket = row >> sh, local = row & (2^sh - 1), sh = ceil(log2 T_l) - log2 NB per level.  One shift
+// and one mask instead of five instructions; x-neighbour rows differ in their LOW bits only (r ^ r' = 2^e - 1: the prime of dimension
+// 0 is 1 on hashed levels, r' = r + 1 on dense ones), so a pair leaves its bucket with probability 2^-sh (2^-13 at T = 2^19) instead of
+// 2^-6 -- the unpaired path is all but dead on the hashed levels -- and a bucket owns CONTIGUOUS table rows, which makes the Adam
+// tail of pass 2 a plain stream.  (The round-2 choice of the bits above the low six spread a ray's consecutive cells over the
+// buckets of dense levels; the levels where that matters are the merged ones, whose runs collapse to one record anyway.)
+//
+// ONE LDS atomic per record in pass 1: the returning ds_add_rtn_u32 that counts a bucket also hands the record its rank inside the
+// bucket; after the scan the slot is start[bucket] + rank (a plain LDS read).  Pass 2 converts to fixed point on the integer pipe:
+// with kFixHead2 = 26 a record (up to 16 merged contributions) stays below 2^30, so v * 2^shift -> v_cvt_i32_f32 -> sign extension
+// replaces the fp64 route (26 significant bits below the step's largest gradient: two more than the fp32 mantissa the atomic path sums with).
+#pragma once
+
+#include "scatter_binned.h"
+
+namespace naf {
+
+struct __attribute__((aligned(8))) PairFx {
+    uint32_t head, pay;
+};
+constexpr uint32_t kFxLocalBits = 13u, kFxBits = 15u;
+constexpr uint32_t kFxEShift = kFxLocalBits, kFxShift = kFxLocalBits + 4u;
+constexpr int kFixHead2 = 26;
+
+__device__ __forceinline__ int fixed_shift2(uint32_t gmax_bits) {
+    const int e = (int)((gmax_bits >> 23) & 0xffu);          // biased exponent of gmax; 0 -> all gradients are zero
+    if (e == 0 || e == 255) return 0;
+    const int s = kFixHead2 - (e - 127) - 1;
+    return s > 120 ? 120 : s;                                 // 2^shift must be an fp32 (gradients below 2^-94: their low bits are not missed)
+}
+
+// rows a bucket of a level with T rows owns: [bucket << sh, (bucket + 1) << sh)
+__host__ __device__ __forceinline__ uint32_t bucket_shift(uint32_t T, uint32_t log2_nb) {
+    uint32_t bits = 0u;
+    while (bits < 32u && (1ull << bits) < (unsigned long long)T) ++bits;      // ceil(log2 T); scalar, once per level
+    return bits > log2_nb ? bits - log2_nb : 0u;
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 pk;
+    pk[0] = (__bf16)lo;
+    pk[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, pk);
+}
+
+// A record that found its tile's block full (see scatter_binned.h: never at T = 2^19, rare single tiles at T = 2^22, every tile under
+// NAF_CFG_TEST_TINY_BLOCKS): straight to the gradient table with float atomics.  Out of line: the hot path keeps its registers.
+__device__ __attribute__((noinline)) void spill_record(float *__restrict__ gg, uint32_t row_a, uint32_t head, uint32_t pay) {
+    const uint32_t e = (head >> kFxEShift) & 15u;
+    const uint32_t row_b = row_a ^ ((1u << e) - 1u);
+    const float fx = (float)(head >> kFxShift) * (1.0f / 32768.0f);
+    const float p0 = __uint_as_float(pay << 16), p1 = __uint_as_float(pay & 0xffff0000u);
+    const float b0 = p0 * fx, b1 = p1 * fx;
+    atomicAdd(gg + (size_t)row_a * 2u, p0 - b0);
+    atomicAdd(gg + (size_t)row_a * 2u + 1u, p1 - b1);
+    if (e != 0u) {
+        atomicAdd(gg + (size_t)row_b * 2u, b0);
+        atomicAdd(gg + (size_t)row_b * 2u + 1u, b1);
+    }
+}
+
+// ---- pass 1 ---------------------------------------------------------------------------------------------------
+// LDS: hist[NB] | start[NB] | total (4 dwords) | staging[slots] records.  One workgroup = one tile of NT x 2 points x LV levels.
+// Per level: (A) every thread builds the records of its points in registers; ds_add_rtn_u32 on the bucket's counter returns the
+// record's rank, (B) wave 0 turns the counters into exclusive offsets and publishes (start, length) of every run, (C) every record
+// goes to staging[start[bucket] + rank], (D) the dense, bucket-sorted block leaves for HBM as whole 128-byte lines.
+template <uint32_t NT, uint32_t LV>
+__global__ void __launch_bounds__(NT, 4)                       // 512 threads: two workgroups per CU; 1024: one -- 16 waves either way
+scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
+                    PairFx *__restrict__ blocks, uint32_t *__restrict__ runs, uint32_t *__restrict__ overflow, uint32_t B, uint32_t H,
+                    uint32_t level_base, uint32_t n_levels, BinPlan plan, SlabReduce slab_job) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x >= plan.n_tiles) {                              // spare workgroups: the MLP backward's slab reduction (scatter_binned.h)
+        if (blockIdx.y == 0u && slab_job.slabs != nullptr)
+            slab_reduce_block<NT / kReduceParams>(reinterpret_cast<float (*)[kReduceParams]>(smem), slab_job, blockIdx.x - plan.n_tiles, threadIdx.x);
+        return;
+    }
+    constexpr uint32_t PTS = 2u;
+    const uint32_t NB = 1u << plan.log2_nb, SLOTS = plan.slots;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *start = hist + NB;
+    uint32_t *total_p = start + NB;                                // 4 dwords (keeps the staging block 16-byte aligned)
+    uint2 *staging = reinterpret_cast<uint2 *>(total_p + 4);       // [SLOTS]
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) hist[i] = 0u;
+
+    float x[PTS][3];
+    uint32_t bp[PTS];
+    bool valid[PTS];
+#pragma unroll
+    for (uint32_t q = 0; q < PTS; ++q) {
+        const uint32_t b_raw = (tile * PTS + q) * NT + threadIdx.x;
+        valid[q] = b_raw < B;
+        bp[q] = valid[q] ? b_raw : B - 1u;
+        src.get(bp[q], x[q]);
+    }
+    const float spacing = src.sample_spacing();
+    uint32_t graw[PTS];                                            // this level's feature gradients (2 x bf16), requested one level ahead
+    if (blockIdx.y * LV < n_levels) {
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) graw[q] = *reinterpret_cast<const uint32_t *>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + bp[q]) * 2u);
+    }
+    __syncthreads();
+    uint32_t n_overflow = 0, n_overflow_level = 0;
+
+    for (uint32_t it = 0; it < LV; ++it) {
+        const uint32_t ly = blockIdx.y * LV + it;
+        if (ly >= n_levels) break;                                   // uniform
+        const uint32_t level = level_base + ly;
+        const LevelMeta m = make_level_meta<3>(offsets, level, H);
+        float *__restrict__ gg = grad_table + (size_t)m.offset * 2u;
+        const uint32_t sh = bucket_shift(m.size, plan.log2_nb), lmask = (1u << sh) - 1u;
+        // merge runs of equal cells inside the wave where cells are at least two sample spacings wide (an invariant of the level, see
+        // scatter_binned.h: fewer than 2^16 cells per axis, so that the cell key packs); their records are singles
+        const bool merging = m.scale * spacing < 0.5f && m.scale < 65535.0f;
+
+        // ---- A: records (registers) + rank inside the bucket ------------------------------------------------------------------
+        uint32_t head[PTS][4], pay[PTS][4], bkt[PTS][4], rank[PTS][4];
+        uint32_t head_b[PTS][4], pay_b[PTS][4], bkt_b[PTS][4], rank_b[PTS][4];      // second corner as a record of its own (single[][])
+        bool on[PTS], single[PTS][4];
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) {
+            float g[2];
+            g[0] = valid[q] ? __uint_as_float(graw[q] << 16) : 0.0f;
+            g[1] = valid[q] ? __uint_as_float(graw[q] & 0xffff0000u) : 0.0f;
+            // SrcRays guarantees coordinates in [0, 1]: pos >= 0.5, so the conversion IS the floor and v_fract the fraction (locate()
+            // spells out the reference's behaviour for coordinates nobody checked; a NaN lands in cell 0 with a NaN fraction there too)
+            float frac[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) {
+                const float pos = __fmaf_rn(x[q][d], m.scale, 0.5f);
+                pg[d] = (uint32_t)pos;
+                frac[d] = __builtin_amdgcn_fractf(pos);
+            }
+            uint32_t ra[4], xm[4];                                   // row of the first corner of pair k, xor distance to the second
+            bool formed[4];                                          // xm has the form 2^e - 1 (always, except behind a true modulo)
+            dispatch_mode<true>(m.mode, [&](auto mode_tag) {
+                constexpr uint32_t MODE = decltype(mode_tag)::value;
+                if constexpr (is_hash_mode(MODE)) {
+                    const uint32_t ty0 = pg[1] * kPrime1, ty1 = ty0 + kPrime1, tz0 = pg[2] * kPrime2, tz1 = tz0 + kPrime2;
+                    const uint32_t h[4] = {ty0 ^ tz0, ty1 ^ tz0, ty0 ^ tz1, ty1 ^ tz1};
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        if constexpr (MODE == kHashMask) {
+                            ra[k] = (pg[0] ^ h[k]) & (m.size - 1u);
+                            xm[k] = (pg[0] ^ (pg[0] + 1u)) & (m.size - 1u);
+                            formed[k] = true;
+                        } else {
+                            ra[k] = (pg[0] ^ h[k]) % m.size;
+                            xm[k] = ra[k] ^ (((pg[0] + 1u) ^ h[k]) % m.size);
+                            formed[k] = (xm[k] & (xm[k] + 1u)) == 0u;
+                        }
+                    }
+                } else {
+                    const uint32_t ty0 = pg[1] * m.stride1, tz0 = pg[2] * m.stride2;
+                    const uint32_t base = pg[0] + ty0 + tz0;
+                    const uint32_t raw[4] = {base, base + m.stride1, base + m.stride2, base + m.stride1 + m.stride2};
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        uint32_t rb;
+                        if constexpr (MODE == kDenseNoMod) { ra[k] = raw[k]; rb = raw[k] + 1u; formed[k] = true; }
+                        else if constexpr (MODE == kDenseMask) { ra[k] = raw[k] & (m.size - 1u); rb = (raw[k] + 1u) & (m.size - 1u); formed[k] = true; }
+                        else { ra[k] = raw[k] % m.size; rb = (raw[k] + 1u) % m.size; }
+                        xm[k] = ra[k] ^ rb;
+                        if constexpr (MODE == kDenseMod) formed[k] = (xm[k] & (xm[k] + 1u)) == 0u;
+                    }
+                }
+            });
+            const float wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+            const float fx = frac[0], gx = 1.0f - frac[0];
+            const uint32_t fxq = (uint32_t)(fx * 32768.0f);          // < 32768: fx < 1
+            on[q] = valid[q];
+            if (merging) {
+                // all eight corner contributions, merged over each run of equal cells with a segmented inclusive scan on DPP row
+                // shifts (runs cut at 16-lane rows; scatter_binned.h); only the last lane of a run emits, as eight singles
+                float va[4][2], vb[4][2];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const float wyz = wy[k & 1u] * wz[k >> 1];
+#pragma unroll
+                    for (uint32_t c = 0; c < 2; ++c) { const float p = wyz * g[c]; va[k][c] = p * gx; vb[k][c] = p * fx; }
+                }
+                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2] | (valid[q] ? 0u : 0x80000000u);
+                const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
+                const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
+                const uint32_t first = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
+                const uint32_t len = lane - first;
+                auto fold = [&](auto shift_tag) {
+                    constexpr uint32_t d = decltype(shift_tag)::value;
+                    const float take = len >= d ? 1.0f : 0.0f;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+#pragma unroll
+                        for (uint32_t c = 0; c < 2; ++c) {
+                            va[k][c] = __builtin_fmaf(dpp_row_shr<d>(va[k][c]), take, va[k][c]);
+                            vb[k][c] = __builtin_fmaf(dpp_row_shr<d>(vb[k][c]), take, vb[k][c]);
+                        }
+                };
+                fold(std::integral_constant<uint32_t, 1>{});
+                fold(std::integral_constant<uint32_t, 2>{});
+                fold(std::integral_constant<uint32_t, 4>{});
+                fold(std::integral_constant<uint32_t, 8>{});
+                on[q] = valid[q] && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t rb = ra[k] ^ xm[k];
+                    single[q][k] = true;
+                    head[q][k] = ra[k] & lmask; bkt[q][k] = ra[k] >> sh; pay[q][k] = pack_bf16x2(va[k][0], va[k][1]);
+                    head_b[q][k] = rb & lmask; bkt_b[q][k] = rb >> sh; pay_b[q][k] = pack_bf16x2(vb[k][0], vb[k][1]);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const float wyz = wy[k & 1u] * wz[k >> 1];
+                    const float p0 = wyz * g[0], p1 = wyz * g[1];
+                    single[q][k] = !(formed[k] && xm[k] <= lmask);
+                    bkt[q][k] = ra[k] >> sh;
+                    const uint32_t e = (uint32_t)__builtin_popcount(xm[k]);
+                    head[q][k] = (ra[k] & lmask) | (single[q][k] ? 0u : (e << kFxEShift) | (fxq << kFxShift));
+                    pay[q][k] = single[q][k] ? pack_bf16x2(p0 * gx, p1 * gx) : pack_bf16x2(p0, p1);
+                    const uint32_t rb = ra[k] ^ xm[k];
+                    head_b[q][k] = rb & lmask; bkt_b[q][k] = rb >> sh; pay_b[q][k] = pack_bf16x2(p0 * fx, p1 * fx);
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                rank[q][k] = rank_b[q][k] = 0u;
+                if (on[q]) {
+                    rank[q][k] = atomicAdd(&hist[bkt[q][k]], 1u);                       // ds_add_rtn_u32
+                    if (single[q][k]) rank_b[q][k] = atomicAdd(&hist[bkt_b[q][k]], 1u);
+                }
+            }
+        }
+        // the next level's gradients: requested here, consumed right after the barrier and before this level's stores are issued (vmcnt
+        // retires in order: a wait placed behind the stores would sit out their round trip -- scatter_binned.h)
+        if (it + 1u < LV && ly + 1u < n_levels) {
+#pragma unroll
+            for (uint32_t q = 0; q < PTS; ++q) graw[q] = *reinterpret_cast<const uint32_t *>(grad + ((size_t)(level + 1u) * B + bp[q]) * 2u);
+        }
+        lds_barrier();
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) asm volatile("" : "+v"(graw[q]) : : "memory");      // pin the wait here
+
+        // ---- B: counters -> exclusive offsets (wave 0: NB / 64 consecutive buckets per lane), run words, total ----------------------
+        if (wave == 0u) {
+            const uint32_t per = NB >> 6;
+            uint32_t mine = 0u;
+            for (uint32_t j = 0; j < per; ++j) mine += hist[lane * per + j];
+            uint32_t incl = mine;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            uint32_t run_start = incl - mine;
+            for (uint32_t j = 0; j < per; ++j) {
+                const uint32_t b = lane * per + j, n = hist[b];
+                start[b] = run_start;
+                hist[b] = 0u;                                            // ready for the next level
+                const uint32_t start_c = min(run_start, SLOTS), n_c = min(n, SLOTS - start_c);      // what fits the block
+                runs[run_index(plan, ly, b, tile)] = start_c | (n_c << 16);
+                run_start += n;
+            }
+            if (lane == 63u) total_p[0] = incl;
+        }
+        lds_barrier();
+
+        // ---- C: placement -------------------------------------------------------------------------------------------------
+        auto place = [&](uint32_t b, uint32_t r, uint32_t h, uint32_t p) __attribute__((always_inline)) {
+            const uint32_t pos = start[b] + r;
+            if (pos < SLOTS) staging[pos] = make_uint2(h, p);
+            else {
+                spill_record(gg, (b << sh) | (h & lmask), h, p);
+                ++n_overflow;
+                ++n_overflow_level;
+            }
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) {
+            if (!on[q]) continue;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                place(bkt[q][k], rank[q][k], head[q][k], pay[q][k]);
+                if (single[q][k]) place(bkt_b[q][k], rank_b[q][k], head_b[q][k], pay_b[q][k]);
+            }
+        }
+        lds_barrier();
+
+        // ---- D: the dense block leaves as whole 128-byte lines (16 bytes per lane; stale slots past the end are harmless) -----
+        {
+            const uint32_t n_rec = min(total_p[0], SLOTS);
+            const uint32_t n_chunk = min(((n_rec * 8u + 127u) >> 7) << 3, (SLOTS * 8u) >> 4);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 *__restrict__ dst = reinterpret_cast<u32x4 *>(blocks + block_index(plan, ly, tile));
+            const u32x4 *from = reinterpret_cast<const u32x4 *>(staging);
+            // non-temporal: written once, read once by pass 2 -- kept out of the Infinity Cache they leave the optimiser state there
+            for (uint32_t c = threadIdx.x; c < n_chunk; c += NT) __builtin_nontemporal_store(from[c], dst + c);
+        }
+        if (__ballot(n_overflow_level != 0u)) {                          // diagnostics: overflow per level (overflow[1 + level])
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) n_overflow_level += __shfl_xor(n_overflow_level, off, 64);
+            if (lane == 0u) atomicAdd(overflow + 1u + level, n_overflow_level);
+            n_overflow_level = 0u;
+        }
+        // no barrier here: the next level touches only `hist` (cleared in B) before its first barrier and writes `start` / the staging
+        // block after it -- every wave has finished this copy before it arrives there
+    }
+    if (__ballot(n_overflow != 0u)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_overflow += __shfl_xor(n_overflow, off, 64);
+        if (lane == 0u) atomicAdd(overflow, n_overflow);
+    }
+}
+
+}  // namespace naf

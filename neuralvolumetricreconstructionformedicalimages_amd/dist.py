@@ -36,15 +36,35 @@ def init_from_env(device_type="cuda"):
         backend = os.environ.get("NAF_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
             torch.cuda.set_device(local_device_index())
-        # Rank 0 evaluates alone (a 1024^2 projection + a 512^3 .. 1024^3 volume query) while the other ranks wait at the barrier
-        # behind it: the collective timeout must outlast an evaluation, not a training step (NAF_DIST_TIMEOUT_MIN, default 2 h)
+        # The training group keeps the backend's default timeout (NAF_DIST_TIMEOUT_MIN overrides it): a dead rank or mismatched
+        # collectives in a training step surface in minutes.  What must outlast an evaluation is only the wait of the other ranks while
+        # rank 0 evaluates alone (a 1024^2 projection + a 512^3 .. 1024^3 volume query): `wait_for_rank0` below, on a group of its own.
         import datetime
-        timeout = datetime.timedelta(minutes=float(os.environ.get("NAF_DIST_TIMEOUT_MIN", "120")))
+        kw = {}
+        if "NAF_DIST_TIMEOUT_MIN" in os.environ:
+            kw["timeout"] = datetime.timedelta(minutes=float(os.environ["NAF_DIST_TIMEOUT_MIN"]))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index()), timeout=timeout)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index()), **kw)
         else:
-            dist.init_process_group(backend, timeout=timeout)
+            dist.init_process_group(backend, **kw)
     return rank, world, local_rank, dist.group.WORLD
+
+
+_EVAL_GROUP = None
+
+
+def wait_for_rank0(group=None):
+    """Barrier for the ranks that wait while rank 0 evaluates or checkpoints alone: a gloo group of its own with a long timeout
+    (NAF_DIST_EVAL_TIMEOUT_MIN, default 2 h), created at the first call by every rank -- the waiters block on the host instead of
+    spinning in a device collective, and the training group's collectives keep their short timeout."""
+    global _EVAL_GROUP
+    if group is None or dist.get_world_size(group) == 1:
+        return
+    if _EVAL_GROUP is None:
+        import datetime
+        minutes = float(os.environ.get("NAF_DIST_EVAL_TIMEOUT_MIN", "120"))
+        _EVAL_GROUP = dist.new_group(ranks=list(range(dist.get_world_size())), backend="gloo", timeout=datetime.timedelta(minutes=minutes))
+    dist.barrier(group=_EVAL_GROUP)
 
 
 def shard_range(n_items, rank, world):

@@ -54,6 +54,7 @@ class NAFEngine:
             dp_mode = naf_dist.pick_dp_mode(self.world, enc.num_levels, enc.level_dim, enc.embeddings.numel(), pts, feat_bytes,
                                             4 if table_dtype == torch.float32 else 2)
         self.dp_mode = dp_mode
+        self._rays_hint = None if rays_per_step_hint is None else int(rays_per_step_hint)
         self.scatter_mode, self.cfg_flags = scatter_mode, cfg_flags     # None: fused.scatter_mode() default (auto)
         # single-GPU, single-stream steps let the gradient reducer apply the table's Adam update itself (naf_render_train_adam:
         # the gradient table is neither written, re-read nor cleared; bit-identical to backward() + optimizer_step())
@@ -199,13 +200,14 @@ class NAFEngine:
         else:
             dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.process_group)
 
-    def _train_step_levels(self, rays, target, weight, t_rand, ray_base, rays_all=None):
+    def _train_step_levels(self, rays, target, weight, t_rand, ray_base, rays_all=None, global_ray_base=None):
         """One level-parallel step (include/naf_hip.h, naf_levels_*): encode the owned levels for every rank's points -> all-to-all
         -> MLP forward / loss / backward on the own rays -> all-to-all of the feature gradients (+ a 17 KB all-reduce of the MLP
         gradient and the loss behind it, overlapping the scatter) -> scatter + Adam on the owned levels.  Same result as the
         data-parallel step and as one process on the concatenated batch.  Every rank must bring the same number of rays; the
-        jitter index of ray j of rank k is ray_base - rank * n + k * n + j (the convention ray_base = (step * world + rank) * n of
-        trainer.py / bench.py).  `rays_all` [world * n, 8]: all ranks' rays in rank order when the caller has them (a shared pixel
+        jitter index of ray j of rank k is global_ray_base + k * n + j; `global_ray_base` defaults to ray_base - rank * n (the convention
+        ray_base = (step * world + rank) * n of trainer.py / bench.py) -- a caller with another convention for ray_base passes it
+        explicitly (the same value on every rank).  `rays_all` [world * n, 8]: all ranks' rays in rank order when the caller has them (a shared pixel
         draw); otherwise they are all-gathered (32 KB per rank)."""
         import torch.distributed as dist
         N, r, grp, lv = self.world, self.rank, self.process_group, self._lv
@@ -217,14 +219,26 @@ class NAFEngine:
         if n == 0:
             raise ValueError("dp_mode 'levels': every rank needs the same, non-zero number of rays per step")
         main = torch.cuda.current_stream(self.device)
-        if lv.get("checked_n") != n:
-            # a new batch size: every rank must bring the same number of rays (the collectives use equal splits) -- checked once per size
-            both = torch.tensor([n, -n], device=self.device, dtype=torch.int64)
-            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=grp)
-            if int(both[0]) != n or int(both[1]) != -n:
-                raise ValueError(f"dp_mode 'levels': ranks hold different numbers of rays this step (this rank {n}, largest {int(both[0])}, "
-                                 f"smallest {-int(both[1])}); use dp_mode 'sharded' for uneven shards")
-            lv["checked_n"] = n
+        fixed = lv.get("n")
+        if fixed is None:
+            # The first step fixes the batch size of the run.  Every rank has its first step at the same time, so the cross-rank check
+            # below is issued by ALL ranks or by none (a per-size cache would let one rank skip a collective another rank issues --
+            # mismatched collectives, i.e. a hang until the group's timeout); with a rays_per_step_hint (the YAML's n_rays / world:
+            # trainer.py, bench.py) the size is validated locally and no collective is needed at all.
+            if self._rays_hint is not None:
+                if n != self._rays_hint:
+                    raise ValueError(f"dp_mode 'levels': this rank brought {n} rays, the engine was built for {self._rays_hint} per rank "
+                                     f"and step (rays_per_step_hint); use dp_mode 'sharded' for uneven shards")
+            else:
+                both = torch.tensor([n, -n], device=self.device, dtype=torch.int64)
+                dist.all_reduce(both, op=dist.ReduceOp.MAX, group=grp)
+                if int(both[0]) != n or int(both[1]) != -n:
+                    raise ValueError(f"dp_mode 'levels': ranks hold different numbers of rays this step (this rank {n}, largest {int(both[0])}, "
+                                     f"smallest {-int(both[1])}); use dp_mode 'sharded' for uneven shards")
+            lv["n"] = n
+        elif n != fixed:
+            raise ValueError(f"dp_mode 'levels': {n} rays in this step, {fixed} in the first one -- a level-parallel run keeps one batch "
+                             f"size per rank (equal-split collectives); use dp_mode 'sharded' for varying or uneven shards")
         if rays_all is None:
             rays_all = torch.empty(N * n, 8, device=self.device)
             dist.all_gather_into_tensor(rays_all, rays.contiguous(), group=grp)
@@ -245,7 +259,8 @@ class NAFEngine:
         b = lv["buf"][key]
         if self.acc is None or self.acc.numel() < n:
             self.acc = torch.empty(n, device=self.device)
-        cfg_all, cfg = self._cfg((ray_base - r * n) & 0xffffffff), self._cfg(ray_base)
+        g_base = (ray_base - r * n) if global_ray_base is None else int(global_ray_base)
+        cfg_all, cfg = self._cfg(g_base & 0xffffffff), self._cfg((g_base + r * n) & 0xffffffff)
         ws = fused.workspace(cfg_all, N * n * S, self.device)
         lib, sp = _abi.lib(), _abi.stream_ptr()
         marks = []
@@ -625,17 +640,17 @@ class NAFEngine:
                                               float(self.net.bound), cfg.seed, int(ray_base), _abi.stream_ptr()), "sample_rays")
         return z
 
-    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None):
+    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None, global_ray_base=None):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync).  `raw_noise_std` > 0 (render.py:196-199): the per-sample noise on sigma adds sum_s noise_s * dist_s to a
         ray's line integral and nothing else (render.noise_line_integral), so the step runs on target - that term; `noise`: explicit
-        N(0, 1) draws [n, S] instead of torch.randn."""
+        N(0, 1) draws [n, S] instead of torch.randn.  `rays_all` / `global_ray_base`: level-parallel steps only (_train_step_levels)."""
         n = rays.shape[0]
         if float(raw_noise_std) > 0.0 and n > 0:
             from .render import noise_line_integral
             target = target - noise_line_integral(rays, self.sample_depths(rays, t_rand, ray_base), raw_noise_std, noise)
         if self.dp_mode == "levels" and self.process_group is not None:
-            self._train_step_levels(rays, target, weight, t_rand, ray_base, rays_all)
+            self._train_step_levels(rays, target, weight, t_rand, ray_base, rays_all, global_ray_base)
         elif self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
             self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
         else:

@@ -138,8 +138,10 @@ class Trainer:
             self.engine = NAFEngine(self.net, cfg["render"]["n_samples"], perturb=cfg["render"]["perturb"],
                                     lr=cfg["train"]["lrate"], betas=(0.9, 0.999),
                                     table_dtype=_DTYPES[backend.get("table_dtype", "float32")], process_group=self.group,
-                                    # levels / sharded by the bytes on the links (dist.pick_dp_mode); level-parallel ranks need equal shards
-                                    dp_mode=backend.get("dp_mode", "auto" if self._even_shards else "sharded"),
+                                    # 'sharded' (gradient reduce-scatter / per-rank Adam / all-gather) unless the YAML's backend.dp_mode asks
+                                    # for 'levels' or 'auto' (dist.pick_dp_mode): the level-parallel step is opt-in until it has run over
+                                    # RCCL on more than one rank; level-parallel ranks need equal shards
+                                    dp_mode=backend.get("dp_mode", "sharded"),
                                     rays_per_step_hint=-(-int(cfg["train"]["n_rays"]) // max(self.world, 1)))
             self.engine.broadcast_parameters()
             self.optimizer = _EngineOptimizer(self.engine)
@@ -204,10 +206,10 @@ class Trainer:
                 msg = "".join(f", {k}: {float(v):.3g}" for k, v in loss_test.items())
                 print(f"[EVAL] epoch: {idx_epoch}/{self.epochs}{msg}")
             if self.group is not None and self.i_eval > 0 and (idx_epoch % self.i_eval == 0 or idx_epoch == self.epochs):
-                # rank 0 evaluated alone: the other ranks wait HERE (a barrier under the long group timeout of dist.init_from_env),
-                # not inside the first gradient exchange of the next step
-                import torch.distributed as tdist
-                tdist.barrier(group=self.group)
+                # rank 0 evaluated alone: the other ranks wait HERE (a host-side barrier on a group with a long timeout of its own,
+                # dist.wait_for_rank0), not inside the first gradient exchange of the next step
+                from . import dist as naf_dist
+                naf_dist.wait_for_rank0(self.group)
 
             for data in self._batches():
                 self.global_step += 1

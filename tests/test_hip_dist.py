@@ -237,22 +237,31 @@ def test_bucketed_rccl_path_with_one_rank_equals_plain_step():
         assert r["allreduce_ms_per_step"] >= 0.0 and r["tail_ms_per_step"] > 0.0
 
 
-@pytest.mark.parametrize("rays", [1024, 8192])
-def test_bench_two_rank_launch_rehearsal(rays):
-    """`bench.py --gpus 2` under torch.distributed.run exactly as the driver launches it, except that the two ranks share
-    the one GPU of the test box and talk through gloo (NAF_BENCH_BACKEND / NAF_BENCH_SHARE_GPU rehearsal hooks): one JSON
-    line from rank 0 with the whole-job rate, the MAX-over-ranks time and the all-reduce probe."""
+@pytest.mark.parametrize("rays,dp_mode,direct", [(1024, "auto", True), (1024, "sharded", True), (8192, "sharded", False)])
+def test_bench_two_rank_launch_rehearsal(rays, dp_mode, direct):
+    """`bench.py --gpus 2` as the driver may launch it -- bare (`python bench.py --gpus 2`: bench.py starts torch.distributed.run
+    itself, as a child process) or already under torch.distributed.run -- except that the two ranks share the one GPU of the test
+    box and talk through gloo (NAF_BENCH_BACKEND / NAF_BENCH_SHARE_GPU rehearsal hooks): one JSON line from rank 0 with the
+    whole-job rate, the MAX-over-ranks time and the all-reduce probe."""
     import json
     import socket
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ, NAF_BENCH_BACKEND="gloo", NAF_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", str(rays)]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", str(rays)]
+    if dp_mode != "sharded":                                          # sharded is the default: the driver's command carries no such flag
+        tail += ["--dp-mode", dp_mode]
+    if direct:
+        cmd = [sys.executable, *tail]
+    else:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), *tail]
     res = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -261,15 +270,16 @@ def test_bench_two_rank_launch_rehearsal(rays):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 2 * rays * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert out["allreduce_ms_per_step"] is not None and out["allreduce_exposed_ms_per_step"] is not None and out["rays_per_s_per_gpu"] > 0
-    if rays == 1024:
+    if dp_mode == "auto":
         # the reference's step: fewer bytes cross the links level-parallel (dist.pick_dp_mode): 2 x 1024 x 192 x 32 x 2 B x 1/2 + MLP
         assert out["config"]["parallelism"] == "lp2" and out["grad_exchange"].startswith("level-parallel")
         assert 12_500_000 < out["allreduce_bytes"] < 12_700_000 and set(out["level_parallel_phases_ms"]) >= {"encode_ms", "features_all_to_all_ms"}
     else:
-        # 8 192 rays per GPU: the gradient exchange is the smaller one; 8 192 x 192 samples are above dist.SINGLE_BUCKET_BELOW_POINTS
         assert out["config"]["parallelism"] == "dp2" and out["grad_exchange"].startswith("reduce-scatter")
-        assert out["allreduce_bytes"] > 57_000_000 and out["allreduce_buckets"] == [[8, 16], [0, 8]]
-    assert "cpu_baseline" not in out                               # rank 0 at N = 1 only
+        assert out["allreduce_bytes"] > 57_000_000
+        if rays == 8192:                                              # 8 192 x 192 samples are above dist.SINGLE_BUCKET_BELOW_POINTS
+            assert out["allreduce_buckets"] == [[8, 16], [0, 8]]
+    assert "cpu_baseline" not in out and "full_schedule" in out and out["full_schedule"] is None      # rank 0 at N = 1 only
 
 
 @pytest.mark.parametrize("table_dtype,dp_mode", [("float32", "sharded"), ("bfloat16", "sharded"), ("bfloat16", "levels")])
