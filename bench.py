@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--full-schedule-epochs", type=int, default=None, help="diagnostics: shorten the full schedule")
     ap.add_argument("--scatter-mode", choices=["auto", "atomic", "binned"], default="auto",
                     help="table-gradient scatter: auto = binned from 2^13 points per step on (naf_render_cfg.scatter_mode)")
+    ap.add_argument("--cfg-flags", type=int, default=0, help="diagnostics: extra naf_render_cfg.flags bits (e.g. 2048 = NAF_CFG_SCATTER_PAIR12)")
     ap.add_argument("--per-level", action="store_true", help="diagnostics: one launch per level (NAF_CFG_PER_LEVEL_LAUNCHES)")
     ap.add_argument("--interleaved-levels", action="store_true",
                     help="diagnostics: the encoder walks all levels of a point tile at once (NAF_CFG_LEVELS_INTERLEAVED)")
@@ -423,7 +424,7 @@ def main():
         return make_chest_engine(device, precision, args.lr, group, args.seed,
                                  n_streams=args.streams if group is None else 1, chunk_rays=args.chunk_rays,
                                  scatter_mode={"auto": 0, "atomic": 1, "binned": 2}[args.scatter_mode],
-                                 cfg_flags=(_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
+                                 cfg_flags=args.cfg_flags | (_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
                                            | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOWS if args.windows else 0) | (_abi.CFG_BACKWARD_ONE_WAVE_PER_SIMD if args.bwd_one_wave else 0) | {0: 0, 1: _abi.CFG_ENCODE_LEVEL_MAJOR, 2: _abi.CFG_ENCODE_GROUPS_2, 4: _abi.CFG_ENCODE_GROUPS_4, 8: _abi.CFG_ENCODE_GROUPS_2 | _abi.CFG_ENCODE_GROUPS_4}[args.encode_groups],
                                  bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode,
                                  rays_per_step_hint=args.rays)

@@ -16,16 +16,17 @@ template <int LP>   // 0 none, 1 f16, 2 bf16
 __global__ void __launch_bounds__(256)
 adam_kernel(float *__restrict__ param, float *__restrict__ m, float *__restrict__ v, float *__restrict__ grad,
             void *__restrict__ param_lp, uint64_t n, AdamArgs a, bool zero_grad) {
+    constexpr bool kFast = LP != 0;        // a 16-bit shadow is what the kernels read: adam_math.h
     const uint64_t n4 = n / 4;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(param)[i];
         float4 mm = reinterpret_cast<float4 *>(m)[i];
         float4 vv = reinterpret_cast<float4 *>(v)[i];
         const float4 g = reinterpret_cast<float4 *>(grad)[i];
-        adam_one(p.x, mm.x, vv.x, g.x, a);
-        adam_one(p.y, mm.y, vv.y, g.y, a);
-        adam_one(p.z, mm.z, vv.z, g.z, a);
-        adam_one(p.w, mm.w, vv.w, g.w, a);
+        adam_one<kFast>(p.x, mm.x, vv.x, g.x, a);
+        adam_one<kFast>(p.y, mm.y, vv.y, g.y, a);
+        adam_one<kFast>(p.z, mm.z, vv.z, g.z, a);
+        adam_one<kFast>(p.w, mm.w, vv.w, g.w, a);
         reinterpret_cast<float4 *>(param)[i] = p;
         reinterpret_cast<float4 *>(m)[i] = mm;
         reinterpret_cast<float4 *>(v)[i] = vv;
@@ -44,7 +45,7 @@ adam_kernel(float *__restrict__ param, float *__restrict__ m, float *__restrict_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
         const uint64_t i = n4 * 4 + threadIdx.x;
         float p = param[i], mm = m[i], vv = v[i];
-        adam_one(p, mm, vv, grad[i], a);
+        adam_one<kFast>(p, mm, vv, grad[i], a);
         param[i] = p; m[i] = mm; v[i] = vv;
         if (zero_grad) grad[i] = 0.0f;
         if constexpr (LP == 1) reinterpret_cast<_Float16 *>(param_lp)[i] = (_Float16)p;
@@ -61,6 +62,8 @@ AdamArgs naf::make_adam_args(float lr, float beta1, float beta2, float eps, uint
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
     a.bias1 = (float)(1.0 - std::pow((double)beta1, (double)step));
     a.bias2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+    a.step_size = a.lr / a.bias1;
+    a.inv_bias2_sqrt = 1.0f / a.bias2_sqrt;
     return a;
 }
 

@@ -11,19 +11,32 @@ namespace naf {
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale;
+    float step_size, inv_bias2_sqrt;      // lr / bias1 and 1 / bias2_sqrt (host, make_adam_args): the operands of the kFast form
 };
 
-// torch's operation sequence with correctly rounded sqrt and divisions.  (A form with one hardware reciprocal and the hardware square
-// root -- 1 ulp each, 24 fewer vector instructions per element -- was measured for tables that keep a 16-bit shadow: the reducer's
-// tail is issue-bound at small batches and gained 7 us of 112 at 1 024 rays.  It is not used: the chest run at the reference's
-// learning rate oscillates around 35 dB between 3 and 7 s of training, and the ulp-level change moved the first crossing of that
-// threshold from 3.4 to 7.2 s -- a reminder that the optimiser is the one place where this code follows torch to the rounding.)
+// kFast = false (fp32 tables: the parity mode): torch's operation sequence with correctly rounded sqrt and divisions -- the optimiser
+// follows torch to the rounding there.
+// kFast = true (tables that keep a 16-bit shadow: the value every kernel reads is the update rounded to 8 or 11 significant bits, so
+// an ulp of the fp32 master is three orders of magnitude below what the step can resolve anyway): the same update with the hardware
+// square root and reciprocal (1 ulp each) and fused multiply-adds -- 11 vector instructions per element instead of ~45.  The
+// reducer's Adam tail is issue-bound at the reference's batch (17 M of its 26 M vector instructions per launch were this function,
+// profiles/round3_wave_state.md).  Round 3 measured this form once and dropped it because it moved the FIRST crossing of 35 dB of a
+// curve that oscillates by +-1.5 dB there; on the reference's full schedule (bench.py full_schedule) the final volume PSNR is the
+// figure that counts, and it does not move (profiles/round4_*).
+template <bool kFast = false>
 __device__ __forceinline__ float adam_one(float &p, float &m, float &v, float g, const AdamArgs &a) {
     g *= a.grad_scale;
-    m = m + (g - m) * (1.0f - a.beta1);                    // torch: exp_avg.lerp_(grad, 1-beta1)
-    v = v * a.beta2 + (1.0f - a.beta2) * g * g;            // torch: exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;   // torch: (sqrt(v)/sqrt(bias2)).add_(eps)
-    p = p - (a.lr / a.bias1) * (m / denom);                // torch: param.addcdiv_(m, denom, -lr/bias1)
+    if constexpr (kFast) {
+        m = __builtin_fmaf(g - m, 1.0f - a.beta1, m);
+        v = __builtin_fmaf((1.0f - a.beta2) * g, g, v * a.beta2);
+        const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), a.inv_bias2_sqrt, a.eps);
+        p = __builtin_fmaf(-a.step_size * m, __builtin_amdgcn_rcpf(denom), p);
+    } else {
+        m = m + (g - m) * (1.0f - a.beta1);                    // torch: exp_avg.lerp_(grad, 1-beta1)
+        v = v * a.beta2 + (1.0f - a.beta2) * g * g;            // torch: exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;   // torch: (sqrt(v)/sqrt(bias2)).add_(eps)
+        p = p - (a.lr / a.bias1) * (m / denom);                // torch: param.addcdiv_(m, denom, -lr/bias1)
+    }
     return p;
 }
 

@@ -26,6 +26,7 @@
 #include "fused_forward.h"
 #include "mlp_slabs.h"
 #include "scatter_binned.h"
+#include "scatter_v2.h"
 
 namespace naf {
 
@@ -808,8 +809,13 @@ constexpr uint64_t kBinMinPoints = 1u << 13;             // measured: 128 rays x
 constexpr size_t kBinBudgetBytes = (size_t)40 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
                                                          // step fit, so the reducer gets 1024 workgroups to balance over 256 CUs
 
+// The canonical shape (two bf16 channels) takes the compact 8-byte records and the kernels of scatter_v2.h
+static bool scatter_v2(const naf_render_cfg *cfg) {
+    return cfg->mlp_precision == NAF_BF16 && cfg->C == 2u && (cfg->flags & NAF_CFG_SCATTER_PAIR12) == 0u;
+}
 // bytes of a pair record (scatter_binned.h): head + two corners x C values (fp32 in parity mode, bf16 packed in pairs otherwise)
 static size_t record_bytes(const naf_render_cfg *cfg) {
+    if (scatter_v2(cfg)) return sizeof(PairFx);
     return cfg->mlp_precision == NAF_F32 ? 4u * (1u + 2u * cfg->C) : 4u * (1u + 2u * ((cfg->C + 1u) / 2u));
 }
 // pass-1 tile shape, the host mirror of BinShape<Rec>
@@ -891,7 +897,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1248,6 +1254,65 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
     return NAF_OK;
 }
 
+// The same launch plan with the kernels of scatter_v2.h (8-byte records; the canonical two-channel bf16 shape).
+static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
+                               const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
+                               const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
+    constexpr uint32_t NT = 512u, PTS = 2u, kLvMany = 16u, kLvFew = 4u;
+    const BinPlan &plan = w.plan;
+    const bool big = plan.tile_points == 2u * NT * PTS;
+    if (!big && plan.tile_points != NT * PTS) return fail(NAF_ERR_LAUNCH, "binned scatter: plan / kernel tile mismatch");
+    const uint32_t threads = big ? 2u * NT : NT;
+    const bool many = plan.n_tiles >= (big ? 768u : 1536u);
+    const uint32_t LV = many ? kLvMany : kLvFew;
+    auto bin = big ? (many ? scatter_bin2_kernel<2u * NT, kLvMany> : scatter_bin2_kernel<2u * NT, kLvFew>)
+                   : (many ? scatter_bin2_kernel<NT, kLvMany> : scatter_bin2_kernel<NT, kLvFew>);
+    const bool fast = adam != nullptr && adam->lp != nullptr;        // tables with a 16-bit shadow: adam_math.h
+    auto red = adam == nullptr ? scatter_reduce2_kernel<false, false> : fast ? scatter_reduce2_kernel<true, true> : scatter_reduce2_kernel<true, false>;
+    const AdamTail tail = adam != nullptr ? *adam : AdamTail{};
+    const uint32_t NB = 1u << plan.log2_nb;
+    const uint32_t red_lds = plan.max_local_rows * 2u * 8u;
+    const uint32_t bin_lds = (2u * NB + 4u) * 4u + plan.slots * (uint32_t)sizeof(PairFx) + (plan.slots / 2u) * 12u;      // + the side list
+    if (int rc = raise_lds_limit(red, red_lds, "binned scatter: cannot raise dynamic LDS limit (reduce)")) return rc;
+    if (int rc = raise_lds_limit(bin, bin_lds, "binned scatter: cannot raise dynamic LDS limit (bin)")) return rc;
+    static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
+    static const char *const red_names[32] = NAF_LEVEL_NAMES("scatter_reduce_kernel_L");
+    const bool per_level = per_level_launches(cfg);
+    SlabReduce job{};
+    if (slab_job != nullptr) job = *slab_job;
+    auto launch_bin = [&](uint32_t l0, uint32_t nl) -> int {
+        ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
+        const uint32_t spare = job.slabs != nullptr ? kSlabReduceBlocks : 0u;
+        hipLaunchKernelGGL(bin, dim3(plan.n_tiles + spare, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const uint16_t *)dfeat,
+                           offsets, grad_table, (PairFx *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job);
+        job = SlabReduce{};
+        return check_launch("scatter_bin_kernel");
+    };
+    auto launch_reduce = [&](uint32_t l0, uint32_t ly0, uint32_t nl) -> int {
+        ProfScope prof_(per_level ? level_name(red_names, l0 + ly0) : "scatter_reduce_kernel", s);
+        const uint32_t n_split = reducer_split(NB, nl);
+        if (adam != nullptr && n_split != 1u) return fail(NAF_ERR_LAUNCH, "binned scatter: the Adam tail needs unsplit reducer launches");
+        hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const PairFx *)w.regions, w.counts, offsets,
+                           grad_table, w.gmax, l0, ly0, plan, tail);
+        return check_launch("scatter_reduce_kernel");
+    };
+    if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {
+        if (int rc = launch_bin(0u, cfg->L)) return rc;              // data parallel: bin once, finish the table bucket by bucket (see above)
+        for (uint32_t b = 0; b < buckets->n_buckets; ++b) {
+            if (int rc = launch_reduce(0u, buckets->level_begin[b], buckets->level_end[b] - buckets->level_begin[b])) return rc;
+            if (buckets->ready[b] != nullptr && hipEventRecord((hipEvent_t)buckets->ready[b], s) != hipSuccess)
+                return fail(NAF_ERR_LAUNCH, "render_train: cannot record a bucket event");
+        }
+        return NAF_OK;
+    }
+    for (uint32_t l0 = lv_begin; l0 < lv_end; l0 += plan.levels_per_pass) {
+        const uint32_t nl = std::min(plan.levels_per_pass, lv_end - l0);
+        if (int rc = launch_bin(l0, nl)) return rc;
+        if (int rc = launch_reduce(l0, 0u, nl)) return rc;
+    }
+    return NAF_OK;
+}
+
 // Table-gradient scatter of the levels [lv_begin, lv_end).
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
@@ -1255,6 +1320,7 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
                                     const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
+        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
         if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
         return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
     }

@@ -612,7 +612,8 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 const float extra = gg[e];
                 if (extra != 0.0f) { g = extra + g; gg[e] = 0.0f; }          // the order of the separate route: table += sum
             }
-            adam_one(p, m, v, g, adam.a);
+            if (adam.lp != nullptr) adam_one<true>(p, m, v, g, adam.a);          // the form adam_kernel uses for tables with a 16-bit shadow
+            else adam_one<false>(p, m, v, g, adam.a);
             pp[e] = p; pm[e] = m; pv[e] = v;
             if (adam.lp != nullptr) {
                 const size_t el = (size_t)off * C + e;
@@ -654,7 +655,10 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
                 }
                 float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) adam_one(p[j], m[j], v[j], g[j], adam.a);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (adam.lp != nullptr) adam_one<true>(p[j], m[j], v[j], g[j], adam.a);
+                    else adam_one<false>(p[j], m[j], v[j], g[j], adam.a);
+                }
                 *reinterpret_cast<Quad *>(pp + e) = Quad{p[0], p[1], p[2], p[3]};
                 *reinterpret_cast<Quad *>(pm + e) = Quad{m[0], m[1], m[2], m[3]};
                 *reinterpret_cast<Quad *>(pv + e) = Quad{v[0], v[1], v[2], v[3]};

@@ -79,7 +79,7 @@ __device__ __attribute__((noinline)) void spill_record(float *__restrict__ gg, u
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: hist[NB] | start[NB] | total (4 dwords) | staging[slots] records.  One workgroup = one tile of NT x 2 points x LV levels.
+// LDS: hist[NB] | start[NB] | total (4 dwords) | staging[slots] records | side list [slots / 2] x 12 bytes.  One workgroup = one tile of NT x 2 points x LV levels.
 // Per level: (A) every thread builds the records of its points in registers; ds_add_rtn_u32 on the bucket's counter returns the
 // record's rank, (B) wave 0 turns the counters into exclusive offsets and publishes (start, length) of every run, (C) every record
 // goes to staging[start[bucket] + rank], (D) the dense, bucket-sorted block leaves for HBM as whole 128-byte lines.
@@ -98,10 +98,16 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
     const uint32_t NB = 1u << plan.log2_nb, SLOTS = plan.slots;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *start = hist + NB;
-    uint32_t *total_p = start + NB;                                // 4 dwords (keeps the staging block 16-byte aligned)
+    uint32_t *total_p = start + NB;                                // [0] records of the level, [1] length of the side list
     uint2 *staging = reinterpret_cast<uint2 *>(total_p + 4);       // [SLOTS]
+    // Second-corner singles do not travel in registers (eight more record slots per thread for something that happens to 2^-13 of
+    // the pairs on the hashed levels would cost the kernel its occupancy): phase A appends them to a side list in LDS
+    // { bucket << 16 | rank, head, pay } and phase C places them together with everything else.
+    const uint32_t side_cap = SLOTS / 2u;
+    uint32_t *side = reinterpret_cast<uint32_t *>(staging + SLOTS);   // [side_cap][3]
     const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < NB; i += NT) hist[i] = 0u;
+    if (threadIdx.x == 0u) total_p[1] = 0u;
 
     float x[PTS][3];
     uint32_t bp[PTS];
@@ -135,8 +141,19 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
 
         // ---- A: records (registers) + rank inside the bucket ------------------------------------------------------------------
         uint32_t head[PTS][4], pay[PTS][4], bkt[PTS][4], rank[PTS][4];
-        uint32_t head_b[PTS][4], pay_b[PTS][4], bkt_b[PTS][4], rank_b[PTS][4];      // second corner as a record of its own (single[][])
-        bool on[PTS], single[PTS][4];
+        bool on[PTS];
+        // a second corner that travels as a record of its own: counted and ranked like every record, kept in the side list
+        auto emit_b = [&](uint32_t rb, uint32_t p) __attribute__((always_inline)) {
+            const uint32_t i = atomicAdd(&total_p[1], 1u);
+            if (i < side_cap) {
+                const uint32_t b = rb >> sh, r = atomicAdd(&hist[b], 1u);
+                side[3u * i] = (b << 16) | r; side[3u * i + 1u] = rb & lmask; side[3u * i + 2u] = p;
+            } else {                                                 // a tile of nothing but singles with a full list: see spill_record
+                spill_record(gg, rb, 0u, p);
+                ++n_overflow;
+                ++n_overflow_level;
+            }
+        };
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) {
             float g[2];
@@ -223,32 +240,39 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
                 on[q] = valid[q] && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t rb = ra[k] ^ xm[k];
-                    single[q][k] = true;
                     head[q][k] = ra[k] & lmask; bkt[q][k] = ra[k] >> sh; pay[q][k] = pack_bf16x2(va[k][0], va[k][1]);
-                    head_b[q][k] = rb & lmask; bkt_b[q][k] = rb >> sh; pay_b[q][k] = pack_bf16x2(vb[k][0], vb[k][1]);
+                    if (on[q]) emit_b(ra[k] ^ xm[k], pack_bf16x2(vb[k][0], vb[k][1]));
                 }
             } else {
+                // the common case first, for every lane: a pair record per k ...
+                bool single[4], any = false;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
                     const float wyz = wy[k & 1u] * wz[k >> 1];
-                    const float p0 = wyz * g[0], p1 = wyz * g[1];
-                    single[q][k] = !(formed[k] && xm[k] <= lmask);
+                    single[k] = valid[q] && !(formed[k] && xm[k] <= lmask);
+                    any = any || single[k];
                     bkt[q][k] = ra[k] >> sh;
-                    const uint32_t e = (uint32_t)__builtin_popcount(xm[k]);
-                    head[q][k] = (ra[k] & lmask) | (single[q][k] ? 0u : (e << kFxEShift) | (fxq << kFxShift));
-                    pay[q][k] = single[q][k] ? pack_bf16x2(p0 * gx, p1 * gx) : pack_bf16x2(p0, p1);
-                    const uint32_t rb = ra[k] ^ xm[k];
-                    head_b[q][k] = rb & lmask; bkt_b[q][k] = rb >> sh; pay_b[q][k] = pack_bf16x2(p0 * fx, p1 * fx);
+                    head[q][k] = (ra[k] & lmask) | ((uint32_t)__builtin_popcount(xm[k]) << kFxEShift) | (fxq << kFxShift);
+                    pay[q][k] = pack_bf16x2(wyz * g[0], wyz * g[1]);
+                }
+                // ... then the lanes whose corners have different owners (2^-sh of the pairs: a wave-level branch that is almost never
+                // taken on the hashed levels) turn theirs into two singles
+                if (__ballot(any) != 0ull) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        if (single[k]) {
+                            const float wyz = wy[k & 1u] * wz[k >> 1];
+                            const float p0 = wyz * g[0], p1 = wyz * g[1];
+                            head[q][k] = ra[k] & lmask; pay[q][k] = pack_bf16x2(p0 * gx, p1 * gx);
+                            emit_b(ra[k] ^ xm[k], pack_bf16x2(p0 * fx, p1 * fx));
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
-                rank[q][k] = rank_b[q][k] = 0u;
-                if (on[q]) {
-                    rank[q][k] = atomicAdd(&hist[bkt[q][k]], 1u);                       // ds_add_rtn_u32
-                    if (single[q][k]) rank_b[q][k] = atomicAdd(&hist[bkt_b[q][k]], 1u);
-                }
+                rank[q][k] = 0u;
+                if (on[q]) rank[q][k] = atomicAdd(&hist[bkt[q][k]], 1u);                       // ds_add_rtn_u32
             }
         }
         // the next level's gradients: requested here, consumed right after the barrier and before this level's stores are issued (vmcnt
@@ -297,17 +321,20 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         };
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) {
-            if (!on[q]) continue;
+            if (on[q]) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                place(bkt[q][k], rank[q][k], head[q][k], pay[q][k]);
-                if (single[q][k]) place(bkt_b[q][k], rank_b[q][k], head_b[q][k], pay_b[q][k]);
+                for (uint32_t k = 0; k < 4; ++k) place(bkt[q][k], rank[q][k], head[q][k], pay[q][k]);
             }
+        }
+        {
+            const uint32_t n_side = min(total_p[1], side_cap);
+            for (uint32_t i = threadIdx.x; i < n_side; i += NT) place(side[3u * i] >> 16, side[3u * i] & 0xffffu, side[3u * i + 1u], side[3u * i + 2u]);
         }
         lds_barrier();
 
         // ---- D: the dense block leaves as whole 128-byte lines (16 bytes per lane; stale slots past the end are harmless) -----
         {
+            if (threadIdx.x == 0u) total_p[1] = 0u;                      // every wave has read the side list's length (barrier above)
             const uint32_t n_rec = min(total_p[0], SLOTS);
             const uint32_t n_chunk = min(((n_rec * 8u + 127u) >> 7) << 3, (SLOTS * 8u) >> 4);
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -329,6 +356,275 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) n_overflow += __shfl_xor(n_overflow, off, 64);
         if (lane == 0u) atomicAdd(overflow, n_overflow);
+    }
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------------------------
+// One workgroup = one (bucket, level): the table rows [bucket << sh, (bucket + 1) << sh) of the level -- contiguous.  Record phase as in
+// scatter_binned.h (every wave streams one contiguous range of tiles, eight runs in flight per lane, tails of two runs share an
+// instruction); accumulators acc[channel][local row], 64-bit fixed point (ds_add_u64), filled through the integer pipe (see the header).
+// kAdam: the workgroup finishes its rows with their Adam update (naf_render_train_adam) -- a plain stream over contiguous memory,
+// 16 bytes per lane and array (two rows x two channels), operands requested in front of the record phase; kFast picks the form of
+// adam_math.h (tables with a 16-bit shadow).
+__device__ __forceinline__ int cvt_rpi(float v) {                // floor(v + 0.5): one instruction, no bias towards zero
+#ifdef NAF_V2_TRUNC
+    return (int)v;
+#else
+    int i;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(v));
+    return i;
+#endif
+}
+
+template <bool kAdam, bool kFast>
+__global__ void __launch_bounds__(1024)
+scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
+                       float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, uint32_t ly_begin,
+                       BinPlan plan, AdamTail adam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
+    const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
+    const uint32_t sh = bucket_shift(T, plan.log2_nb), row_begin = bucket << sh;
+    if (row_begin >= T) return;                                  // a level smaller than its share of buckets (dense coarse levels): no rows, no records
+    const uint32_t rows = min(T - row_begin, 1u << sh);
+    const uint32_t gbits = *gmax_bits;
+    const int shift = fixed_shift2(gbits);
+    const bool poison = fixed_nonfinite(gbits);
+    const float scale = __uint_as_float((uint32_t)(shift + 127) << 23);               // 2^shift, -102 <= shift <= 120
+    const float scale_fx = __uint_as_float((uint32_t)(shift + 127 - (int)kFxBits) << 23);
+    const uint32_t pitch = plan.max_local_rows, T_ = blockDim.x;
+    unsigned long long *acc0 = reinterpret_cast<unsigned long long *>(smem), *acc1 = acc0 + pitch;
+
+    struct __attribute__((packed, aligned(4))) Quad { float x, y, z, w; };              // level offsets may be odd: 8-byte aligned only
+    constexpr uint32_t kPreQ = kAdam ? 4u : 0u;                  // quads (two rows x two channels) prefetched per thread
+    Quad preq_p[kPreQ ? kPreQ : 1u], preq_m[kPreQ ? kPreQ : 1u], preq_v[kPreQ ? kPreQ : 1u];
+    const uint32_t n_quads = (rows + 1u) >> 1;
+    const size_t e0 = ((size_t)off + row_begin) * 2u;            // first table element of the bucket
+    if constexpr (kPreQ != 0u) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPreQ; ++k) {
+            const uint32_t q = threadIdx.x + k * T_;
+            preq_p[k] = preq_m[k] = preq_v[k] = Quad{0.0f, 0.0f, 0.0f, 0.0f};
+            if (2u * q + 1u < rows) {
+                preq_p[k] = *reinterpret_cast<const Quad *>(adam.param + e0 + 4u * q);
+                preq_m[k] = *reinterpret_cast<const Quad *>(adam.m + e0 + 4u * q);
+                preq_v[k] = *reinterpret_cast<const Quad *>(adam.v + e0 + 4u * q);
+            }
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = T_ >> 6;
+    const size_t run0 = run_index(plan, ly, bucket, 0);
+    const uint32_t split_tiles = (plan.n_tiles + gridDim.z - 1u) / gridDim.z;
+    const uint32_t split_begin = blockIdx.z * split_tiles, split_end = min(plan.n_tiles, split_begin + split_tiles);
+    const uint32_t share = (split_tiles + n_waves - 1u) / n_waves;
+    const uint32_t per_wave = share >= 64u ? (share + 63u) & ~63u : (share + 7u) & ~7u;
+    const uint32_t t_begin = split_begin + wave * per_wave, t_end = min(split_end, t_begin + per_wave);
+    const uint32_t first_runs = t_begin + lane < t_end ? runs[run0 + t_begin + lane] : 0u;
+    {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 *a2 = reinterpret_cast<u64x2 *>(smem);
+        for (uint32_t i = threadIdx.x; i < pitch; i += T_) a2[i] = u64x2{0ull, 0ull};      // pitch * 2 cells of 8 bytes
+    }
+    __syncthreads();
+
+    auto add = [&](const PairFx &r) {
+        const uint32_t la = r.head & ((1u << kFxLocalBits) - 1u);
+        const uint32_t e = (r.head >> kFxEShift) & 15u;
+        const uint32_t lb = la ^ ((1u << e) - 1u);
+        const float t = (float)(r.head >> kFxShift) * scale_fx;                          // f_x * 2^shift
+        const float p0 = __uint_as_float(r.pay << 16), p1 = __uint_as_float(r.pay & 0xffff0000u);
+        const float b0 = p0 * t, b1 = p1 * t;                                            // exact: 8 x 15 bits
+        const float a0 = p0 * scale - b0, a1 = p1 * scale - b1;                          // exact: p * 2^shift * (1 - f_x)
+        atomicAdd(&acc0[la], (unsigned long long)(long long)cvt_rpi(a0));                // ds_add_u64
+        atomicAdd(&acc1[la], (unsigned long long)(long long)cvt_rpi(a1));
+        atomicAdd(&acc0[lb], (unsigned long long)(long long)cvt_rpi(b0));
+        atomicAdd(&acc1[lb], (unsigned long long)(long long)cvt_rpi(b1));
+    };
+    constexpr uint32_t kGroup = 8u, kTail = 32u;
+    if (plan.log2_w < 6u) {
+        // many buckets (T >= 2^20): short runs -- a wave takes G = 64 / W runs per instruction, W lanes each (scatter_binned.h)
+        const uint32_t W = 1u << plan.log2_w, G = 64u >> plan.log2_w, g = lane >> plan.log2_w, j = lane & (W - 1u);
+        constexpr uint32_t kSteps = 4;
+        for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
+            const uint32_t mine = t0 == t_begin ? first_runs : (t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u);
+            const uint32_t n_here = min(64u, t_end - t0);
+            for (uint32_t s0 = 0; s0 < n_here; s0 += kSteps * G) {
+                uint32_t n4[kSteps];
+                const PairFx *b4[kSteps];
+                PairFx r4[kSteps];
+#pragma unroll
+                for (uint32_t u = 0; u < kSteps; ++u) {
+                    const uint32_t tl = s0 + u * G + g;
+                    const uint32_t word = (uint32_t)__shfl((int)mine, (int)min(tl, 63u), 64);
+                    n4[u] = tl < n_here ? word >> 16 : 0u;
+                    b4[u] = blocks + block_index(plan, ly, t0 + min(tl, n_here - 1u)) + (word & 0xffffu);
+                    r4[u] = b4[u][j < n4[u] ? j : 0u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSteps; ++u)
+                    if (j < n4[u]) add(r4[u]);
+#pragma unroll 1
+                for (uint32_t u = 0; u < kSteps; ++u)
+                    for (uint32_t i = W + j; __ballot(i < n4[u]) != 0ull; i += W)
+                        if (i < n4[u]) add(b4[u][i]);
+            }
+        }
+    } else
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
+        const uint32_t mine = t0 == t_begin ? first_runs : (t0 + lane < t_end ? runs[run0 + t0 + lane] : 0u);
+        const uint32_t n_here = min(64u, t_end - t0);
+        for (uint32_t j = 0; j < n_here; j += kGroup) {
+            uint32_t n[kGroup], n_max = 0u;
+            const PairFx *base[kGroup];
+            PairFx ra[kGroup];
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) {
+                const uint32_t tj = min(j + u, n_here - 1u);
+                const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)tj);              // scalar (tj is wave-uniform)
+                n[u] = j + u < n_here ? word >> 16 : 0u;
+                n_max = max(n_max, n[u]);
+                base[u] = blocks + block_index(plan, ly, t0 + tj) + (word & 0xffffu);
+                ra[u] = base[u][lane < n[u] ? lane : 0u];
+            }
+            {
+                constexpr uint32_t kPer = 64u / kTail;                      // runs per tail instruction
+                PairFx rt[kGroup / kPer];
+                uint32_t nt[kGroup / kPer];
+#pragma unroll
+                for (uint32_t q = 0; q < kGroup / kPer; ++q) {
+                    const uint32_t sub = lane / kTail, slot = 64u + (lane % kTail);
+                    nt[q] = n[q * kPer];
+                    const PairFx *bq = base[q * kPer];
+#pragma unroll
+                    for (uint32_t k = 1; k < kPer; ++k) {
+                        nt[q] = sub == k ? n[q * kPer + k] : nt[q];
+                        bq = sub == k ? base[q * kPer + k] : bq;
+                    }
+                    rt[q] = bq[slot < nt[q] ? slot : 0u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    if (lane < n[u]) add(ra[u]);
+#pragma unroll
+                for (uint32_t q = 0; q < kGroup / kPer; ++q)
+                    if (64u + (lane % kTail) < nt[q]) add(rt[q]);
+            }
+            if (n_max > 64u + kTail) {                                      // long runs (clustered tiles, merged levels' singles): the rest, run by run
+#pragma unroll 1
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    for (uint32_t i = 64u + kTail + lane; i < n[u]; i += 64u) add(base[u][i]);
+            }
+        }
+    }
+    __syncthreads();
+
+    float *__restrict__ gg = grad_table + e0;
+    const float nan = __builtin_nanf("");
+    // fixed point -> fp32 of the four sums of a quad (rows 2q, 2q + 1 x channels 0, 1).  Sums that fit 32 bits -- nearly all -- convert
+    // with v_cvt_f32_i32 + v_ldexp_f32: one rounding of the same exact value as the fp64 route; chosen per wave (scatter_binned.h).
+    auto sums = [&](uint32_t q, float (&g)[4]) {
+        const unsigned long long *a0 = &acc0[2u * q], *a1 = &acc1[2u * q];
+        const long long x[4] = {(long long)a0[0], (long long)a1[0], (long long)a0[1], (long long)a1[1]};
+        bool small = true;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) small = small && (x[j] == (long long)(int)x[j]);
+        if (__ballot(!small) == 0ull) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) g[j] = ldexpf((float)(int)x[j], -shift);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) g[j] = (float)ldexp((double)x[j], -shift);
+        }
+        if (poison) g[0] = g[1] = g[2] = g[3] = nan;
+    };
+    if constexpr (kAdam) {
+        // A level whose tiles overflowed their blocks has contributions in the gradient table already (atomics of pass 1): they are
+        // added and cleared here.
+        const bool spilled = adam.overflow[1u + level] != 0u;
+        float *__restrict__ pp = adam.param + e0, *__restrict__ pm = adam.m + e0, *__restrict__ pv = adam.v + e0;
+        auto store_lp = [&](uint32_t el, uint32_t count, const float (&p)[4]) {      // 16-bit shadow of `count` elements from local element `el`
+            if (adam.lp == nullptr) return;
+            uint16_t *lp = reinterpret_cast<uint16_t *>(adam.lp) + e0 + el;
+            uint32_t lo, hi;
+            if (adam.lp_dtype == kAdamLpF16) {
+                const _Float16 h0 = (_Float16)p[0], h1 = (_Float16)p[1], h2 = (_Float16)p[2], h3 = (_Float16)p[3];
+                lo = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                hi = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+            } else {
+                lo = pack_bf16x2(p[0], p[1]);
+                hi = pack_bf16x2(p[2], p[3]);
+            }
+            struct __attribute__((packed, aligned(4))) Half4 { uint32_t lo, hi; };
+            if (count == 4u) *reinterpret_cast<Half4 *>(lp) = Half4{lo, hi};
+            else *reinterpret_cast<uint32_t *>(lp) = lo;
+        };
+        auto finish = [&](uint32_t q, bool prefetched, const Quad &p4, const Quad &m4, const Quad &v4) {
+            if (q >= n_quads) return;
+            float g[4];
+            sums(q, g);
+            if (2u * q + 1u < rows) {
+                Quad P = p4, M = m4, V = v4;
+                if (!prefetched) {
+                    P = *reinterpret_cast<const Quad *>(pp + 4u * q);
+                    M = *reinterpret_cast<const Quad *>(pm + 4u * q);
+                    V = *reinterpret_cast<const Quad *>(pv + 4u * q);
+                }
+                if (spilled) {
+                    const Quad extra = *reinterpret_cast<const Quad *>(gg + 4u * q);
+                    const float x[4] = {extra.x, extra.y, extra.z, extra.w};
+                    bool any = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j)
+                        if (x[j] != 0.0f) { g[j] = x[j] + g[j]; any = true; }          // the order of the separate route: table += sum
+                    if (any) *reinterpret_cast<Quad *>(gg + 4u * q) = Quad{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                float p[4] = {P.x, P.y, P.z, P.w}, m[4] = {M.x, M.y, M.z, M.w}, v[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) adam_one<kFast>(p[j], m[j], v[j], g[j], adam.a);
+                *reinterpret_cast<Quad *>(pp + 4u * q) = Quad{p[0], p[1], p[2], p[3]};
+                *reinterpret_cast<Quad *>(pm + 4u * q) = Quad{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<Quad *>(pv + 4u * q) = Quad{v[0], v[1], v[2], v[3]};
+                store_lp(4u * q, 4u, p);
+            } else {                                          // the bucket's last row when its row count is odd: two elements
+                float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (uint32_t c = 0; c < 2; ++c) {
+                    const uint32_t el = 4u * q + c;
+                    float gc = g[c];
+                    if (spilled) {
+                        const float extra = gg[el];
+                        if (extra != 0.0f) { gc = extra + gc; gg[el] = 0.0f; }
+                    }
+                    float m = pm[el], v = pv[el];
+                    p[c] = pp[el];
+                    adam_one<kFast>(p[c], m, v, gc, adam.a);
+                    pp[el] = p[c]; pm[el] = m; pv[el] = v;
+                }
+                store_lp(4u * q, 2u, p);
+            }
+        };
+#pragma unroll
+        for (uint32_t k = 0; k < kPreQ; ++k) finish(threadIdx.x + k * T_, true, preq_p[k], preq_m[k], preq_v[k]);
+        const Quad none{0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t q = threadIdx.x + kPreQ * T_; q < n_quads; q += T_) finish(q, false, none, none, none);
+    } else {
+        // gradient table += sums: in place and coalesced when this workgroup is the sole owner of its rows, with one fp32 atomic per
+        // element when the bucket's tiles were split between gridDim.z workgroups
+        for (uint32_t q = threadIdx.x; q < n_quads; q += T_) {
+            float g[4];
+            sums(q, g);
+            const uint32_t count = 2u * q + 1u < rows ? 4u : 2u;
+            if (gridDim.z == 1u && count == 4u) {
+                Quad *dst = reinterpret_cast<Quad *>(gg + 4u * q);
+                const Quad old = *dst;
+                *dst = Quad{old.x + g[0], old.y + g[1], old.z + g[2], old.w + g[3]};
+            } else {
+                for (uint32_t j = 0; j < count; ++j) {
+                    if (gridDim.z == 1u) gg[4u * q + j] += g[j];
+                    else atomicAdd(gg + 4u * q + j, g[j]);
+                }
+            }
+        }
     }
 }
 

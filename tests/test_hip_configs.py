@@ -278,6 +278,33 @@ def test_chest_size_bf16_psnr_within_a_tenth_of_a_db_of_fp32_mode():
     assert abs(loss[torch.bfloat16] - loss[torch.float32]) < 0.05 * loss[torch.float32], loss
 
 
+def test_chest_yaml_step_bf16_tracks_the_fp32_mode_for_5000_steps():
+    """The reference's OWN step (config/chest_50.yaml: 1 024 rays of one projection, loss = sum of 200-ray chunk means, lr 1e-3) for
+    5 000 steps from scratch on the 256^3 phantom, in bf16 mode and in the fp32 parity mode, with identical pixel draws and jitter:
+    the reconstructed-volume PSNR must agree within the north star's 0.1 dB at the end (and both runs must have reconstructed
+    something).  bench.py's `full_schedule` record carries the same comparison to the end of the 75 000-step schedule."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda")
+    scan = bench.ChestScan(dev, 1234)
+    n_rays, steps = bench.CHEST["yaml_rays"], 5000
+    rays = torch.empty(n_rays, 8, device=dev)
+    weight, loss_name = bench.step_weights(n_rays, dev)
+    assert loss_name.startswith("chunk_sum")
+    psnr = {}
+    for prec in ("fp32", "bf16"):
+        engine = bench.make_chest_engine(dev, prec, bench.CHEST["lr"], seed=0)
+        for step in range(steps):
+            target, _ = scan.sampler.draw(step, n_rays, rays)
+            engine.train_step(rays, target, weight, ray_base=step * n_rays)
+        psnr[prec] = scan.volume_psnr(engine.net)
+        del engine
+    assert psnr["fp32"] > 26.0, psnr
+    assert abs(psnr["bf16"] - psnr["fp32"]) < 0.1, psnr
+
+
 # ---- coordinates outside [0,1] (the reference stays in bounds for ANY input: index % hashmap_size, hashencoder.cu:74) --
 @pytest.mark.parametrize("layout", ["blc", "lbc"])
 def test_out_of_range_coordinates_follow_the_reference_modulo(layout):
