@@ -84,6 +84,21 @@ int naf_hash_encode_backward(const void *grad, const float *inputs, const void *
                              int calc_grad_inputs, const void *dy_dx, float *grad_inputs, int dtype, int grad_layout,
                              void *stream);
 
+/* E7 with a workspace.  The reference scheme above -- one global float atomic per corner and channel (hashencoder.cu:257-269) --
+ * runs at the memory side's request rate on MI355X (50.7 of 52.9 ms of a 16 384-ray step).  A caller that lends a
+ * workspace gets the two-pass binned scatter of the training path instead: same contract (grad_embeddings += the same sums,
+ * fp32; grad_inputs as above), the sums formed in a fixed order (bit-reproducible), no allocation inside the library.
+ *   naf_hash_encode_workspace_bytes: bytes `naf_hash_encode_backward_ws` needs for this shape, or 0 when the shape is one the
+ *       binned scatter does not cover (D = 2, C = 1 or 8, fewer than 2^13 points): then -- and whenever `workspace` is NULL or too
+ *       small -- naf_hash_encode_backward_ws IS naf_hash_encode_backward.
+ *   log2_hashmap_size: log2 of the largest level (encoder hyper-parameter, hashgrid.py:96); the levels described by `offsets`
+ *       must not exceed it.   workspace: device memory, 256-byte aligned, contents undefined before and after the call.       */
+size_t naf_hash_encode_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t log2_hashmap_size, int dtype);
+int naf_hash_encode_backward_ws(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
+                                float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t H,
+                                int calc_grad_inputs, const void *dy_dx, float *grad_inputs, int dtype, int grad_layout,
+                                uint32_t log2_hashmap_size, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * R2  stratified sampling along rays  (replaces the ATen ops of render.py:87-105)
  *   rays    f32 [n_rays, 8]  = origin(3) direction(3) near far   (tigre.py:248-255)

@@ -90,6 +90,9 @@ SIGNATURES = {
     "naf_profile_collect": (_i32, [ctypes.c_char_p, ctypes.c_size_t]),
     "naf_hash_encode_forward": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _i32, _i32, _vp]),
     "naf_hash_encode_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "naf_hash_encode_workspace_bytes": (ctypes.c_size_t, [_u32, _u32, _u32, _u32, _u32, _i32]),
+    "naf_hash_encode_backward_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _i32, _i32, _u32, _vp,
+                                           ctypes.c_size_t, _vp]),
     "naf_sample_rays": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _f32, _u64, _u32, _vp]),
     "naf_fine_depths": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _u64, _u32, _vp, _vp]),
     "naf_draw_scan_rays": (_i32, [ctypes.POINTER(ScanDraw), _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32,

@@ -27,9 +27,18 @@ template <uint32_t D>
 struct SrcUnit {
     static constexpr bool kInRange = false;     // the reference kernel stays in bounds for any input (index % hashmap_size)
     const float *__restrict__ x;
+    uint32_t n = 0;                             // points behind x (only sample_spacing() looks at it)
     __device__ __forceinline__ void get(uint32_t b, float (&out)[D]) const {
 #pragma unroll
         for (uint32_t d = 0; d < D; ++d) out[d] = x[(size_t)b * D + d];
+    }
+    // distance between the first two points (for the locality heuristic of the binned scatter: consecutive samples of a ray)
+    __device__ __forceinline__ float sample_spacing() const {
+        if (n < 2u) return 1.0f;
+        float m = 0.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) m = fmaxf(m, fabsf(x[D + d] - x[d]));
+        return m;
     }
 };
 

@@ -21,12 +21,14 @@
 
 #include "naf_host.h"
 #include "hash_kernels.h"
+#include "encode_kernel.h"
 #include "field_mlp.h"
 #include "field_mlp16.h"
 #include "fused_forward.h"
 #include "mlp_slabs.h"
 #include "scatter_binned.h"
 #include "scatter_v2.h"
+#include "scatter_host.h"
 
 namespace naf {
 
@@ -782,7 +784,6 @@ static int raise_lds_limit(K kernel, uint32_t bytes, const char *who) {
         return fail(NAF_ERR_LAUNCH, who);
     return NAF_OK;
 }
-static inline bool per_level_launches(const naf_render_cfg *cfg) { return (cfg->flags & NAF_CFG_PER_LEVEL_LAUNCHES) != 0u; }
 
 template <typename P>
 static uint32_t forward_lds_bytes() { return ((MlpShared<P>::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u; }
@@ -805,60 +806,6 @@ struct Workspace {
     size_t bytes;
 };
 
-constexpr uint64_t kBinMinPoints = 1u << 13;             // measured: 128 rays x 192 samples 0.62 ms (atomics) vs 0.36 ms (binned) per step
-constexpr size_t kBinBudgetBytes = (size_t)40 << 30;     // record buffer per pass (HBM is 288 GB): all 16 levels of a 65 536-ray
-                                                         // step fit, so the reducer gets 1024 workgroups to balance over 256 CUs
-
-// The canonical shape (two bf16 channels) takes the compact 8-byte records and the kernels of scatter_v2.h
-static bool scatter_v2(const naf_render_cfg *cfg) {
-    return cfg->mlp_precision == NAF_BF16 && cfg->C == 2u && (cfg->flags & NAF_CFG_SCATTER_PAIR12) == 0u;
-}
-// bytes of a pair record (scatter_binned.h): head + two corners x C values (fp32 in parity mode, bf16 packed in pairs otherwise)
-static size_t record_bytes(const naf_render_cfg *cfg) {
-    if (scatter_v2(cfg)) return sizeof(PairFx);
-    return cfg->mlp_precision == NAF_F32 ? 4u * (1u + 2u * cfg->C) : 4u * (1u + 2u * ((cfg->C + 1u) / 2u));
-}
-// pass-1 tile shape, the host mirror of BinShape<Rec>
-static uint32_t bin_threads(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 12 ? 512u : 256u; }
-static uint32_t bin_points_per_thread(const naf_render_cfg *cfg) { return record_bytes(cfg) <= 20 ? 2u : 1u; }
-constexpr uint32_t kBigTileLog2Nb = 7u;                  // buckets per level from which pass 1 uses its 1024-thread shape
-
-static bool make_bin_plan(const naf_render_cfg *cfg, uint64_t n_points, BinPlan *plan) {
-    if (cfg->scatter_mode == NAF_SCATTER_ATOMIC || cfg->log2_hashmap_size == 0 || cfg->log2_hashmap_size > 28 || n_points == 0) return false;
-    if (cfg->scatter_mode == NAF_SCATTER_AUTO && n_points < kBinMinPoints) return false;
-    const uint64_t maxT = 1ull << cfg->log2_hashmap_size;
-    uint32_t log2_nb = 6;
-    while (((maxT >> log2_nb) * cfg->C * 8u) > (128u << 10)) ++log2_nb;         // reducer rows (64-bit) must fit LDS
-    // NAF_CFG_MIN_BUCKETS: more, smaller buckets on request (a bucket keeps at least 64 rows)
-    const uint32_t want_nb = 6u + ((cfg->flags & NAF_CFG_MIN_BUCKETS_MASK) >> NAF_CFG_MIN_BUCKETS_SHIFT);
-    const uint32_t cap_nb = cfg->log2_hashmap_size >= 12u ? cfg->log2_hashmap_size - 6u : 6u;
-    log2_nb = std::max(log2_nb, std::min(want_nb, cap_nb));
-    const size_t rec = record_bytes(cfg);
-    // Tables of 2^20 rows per level and more need 128 .. 512 buckets (the reducer's rows must fit the LDS), which cuts a
-    // 1024-point tile into runs of 8 .. 32 records -- short, ragged reads in pass 2.  With 12-byte records a 2048-point
-    // tile (ONE workgroup of 1024 threads per CU instead of two of 512: the same 16 waves) still fits the LDS.
-    const bool big = rec <= 12 && log2_nb >= kBigTileLog2Nb;
-    const uint32_t tile = bin_threads(cfg) * bin_points_per_thread(cfg) * (big ? 2u : 1u);
-    plan->tile_points = tile;
-    plan->n_tiles = (uint32_t)((n_points + tile - 1) / tile);
-    plan->log2_nb = log2_nb;
-    // A tile's block holds four pair records per point plus the second halves of unpaired pairs: 1.6 % on average, but ALL
-    // pairs of a ray that keeps an x cell with index 63 mod 64 for its whole length (seen at T = 2^22, where 1.25x was not
-    // always enough).  1.375x; a tile that still fills its block spills the excess to atomics (correct, counted).  More
-    // would fit the LDS next to a second workgroup, but the larger allocation measured 2-3 % slower.  A multiple of 32
-    // records: blocks start on 128-byte lines.
-    plan->slots = std::min<uint32_t>(65504u, ((tile * 11u / 2u) + 31u) & ~31u);
-    if ((cfg->flags & NAF_CFG_TEST_TINY_BLOCKS) != 0u) plan->slots = std::max(32u, tile & ~31u);      // a quarter of a tile's records fit
-    // pass 2 reads a bucket's run of a tile with W lanes: W = the power of two >= 1.25 x the mean run length, at most a wave
-    const uint32_t mean_run = std::max<uint32_t>(1u, (tile * 4u) >> log2_nb);
-    plan->log2_w = 3u;
-    while (plan->log2_w < 6u && (1u << plan->log2_w) < mean_run + mean_run / 4u) ++plan->log2_w;
-    plan->max_local_rows = (uint32_t)((((maxT + (1ull << log2_nb) - 1) >> log2_nb) + 63u) & ~63ull);
-    const size_t per_level = (size_t)plan->n_tiles * plan->slots * rec;
-    plan->levels_per_pass = (uint32_t)std::min<size_t>(cfg->L, std::max<size_t>(1, kBinBudgetBytes / per_level));
-    if (per_level_launches(cfg)) plan->levels_per_pass = 1;
-    return true;
-}
 static Workspace carve(void *base, const naf_render_cfg *cfg, uint64_t n_points) {
     const size_t esz = cfg->mlp_precision == NAF_F32 ? 4 : 2;
     const size_t feat_bytes = ((size_t)n_points * cfg->L * cfg->C * esz + 255) & ~(size_t)255;
@@ -904,177 +851,11 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     return NAF_OK;
 }
 
-// Feature tensors are written in the MLP's operand precision: TT = table storage, P::feat_t = feature storage.
-// The encoder kernel is templated on one storage type for table and output, so when they differ the
-// features are produced by a converting instantiation below.
-__host__ __device__ constexpr uint32_t encode_points_per_thread(uint32_t C) { return C <= 2 ? 4u : C == 4 ? 2u : 1u; }
-
-template <typename TT, typename FT, uint32_t C, typename Src, uint32_t kWindow>        // kWindow: 0 = two gathers per pair, else points per thread
-__global__ void __launch_bounds__(256)
-encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int32_t *__restrict__ offsets,
-              typename FT::store_t *__restrict__ feat, uint32_t B, uint32_t H, uint32_t level_base, uint32_t order, uint32_t n_levels, uint32_t total_levels,
-              uint32_t tiles, uint32_t chunk) {
-    // order 0 -- level-major (large batches): blocks are dispatched x-fastest, so the whole chip works on ONE level at a time and
-    //   that level's slice of the table stays in the L2s (98.6 % hits).
-    // order 1 -- NAF_CFG_LEVELS_INTERLEAVED (diagnostic): the level in x, every XCD walks levels k and k + 8 at once.
-    const uint32_t table_rows = (uint32_t)offsets[total_levels];
-    // order 4 + log2 G -- XCD GROUPS (small and medium batches): the eight XCDs form G groups of 8 / G; group g takes the levels
-    //   g, g + G, ... one after the other and spreads each level's `tiles` workgroup-sized pieces over its XCDs, dispatched in
-    //   order.  A level is then pulled through 8 / G L2s instead of all eight -- at the reference's batch size the table fills are
-    //   most of what the encoder fetches (0.24 GB per launch by PMC: 8 x 28.5 MB) -- while even / odd levels (G = 2) or levels mod 4
-    //   (G = 4) balance within 0.5 % / 4 % (profiles/round3_bench_per_level_16384rays.json); G = 8 (one level per XCD at a time)
-    //   is 14 % off balance however the levels are paired.  Workgroup b sits on XCD b mod 8 (round-robin dispatch: a property
-    //   used for speed only, any placement gives the same bits).
-    uint32_t g_level = 0u, g_block = 0u;
-    bool g_idle = false;
-    if (order >= 4u) {
-        const uint32_t log2g = order - 4u, G = 1u << log2g, per = 8u >> log2g, xcd = blockIdx.x & 7u;
-        const uint32_t u = (blockIdx.x >> 3) * per + (xcd % per);           // piece index inside the group
-        g_level = xcd / per + G * (u / tiles);
-        g_block = u % tiles;
-        g_idle = g_level >= n_levels;                                       // padding workgroups of a grid rounded up to 8
-    }
-    if (g_idle) return;
-    {
-    const uint32_t level = level_base + (order >= 4u ? g_level : order == 1u ? blockIdx.x : blockIdx.y);
-    const uint32_t block_x = order >= 4u ? g_block : order == 1u ? blockIdx.y : blockIdx.x;
-    const uint32_t grid_x = order >= 4u ? tiles : order == 1u ? gridDim.y : gridDim.x;
-    const LevelMeta m = make_level_meta<3>(offsets, level, H);
-    const typename TT::store_t *__restrict__ grid = table + (size_t)m.offset * C;
-    // Where the C features of point b go: [level][B points] -- or, for a level-parallel rank (naf_levels_encode, chunk = points of one
-    // rank), [rank = b / chunk][level - level_base][chunk points]: one contiguous block per destination of the all-to-all.
-    const uint32_t chunk_magic = chunk != 0u ? (uint32_t)(0x100000000ull / chunk) + 1u : 0u;
-    auto slot = [&](uint32_t b) -> size_t {
-        if (chunk == 0u) return (size_t)level * B + b;
-        uint32_t r = __umulhi(b, chunk_magic);               // b / chunk, at most one too large (b < 2^31)
-        r -= r * chunk > b ? 1u : 0u;
-        return ((size_t)r * n_levels + (level - level_base)) * chunk + (b - r * chunk);
-    };
-    dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
-    constexpr uint32_t MODE = decltype(mode_tag)::value;
-    const uint32_t stride = grid_x * blockDim.x;
-    if constexpr (kWindow != 0u) {
-        // x-neighbour corners through one 16-byte window each (PairWindow, naf_device.h): 4.7 instead of 8 L1 accesses per point
-        using PW = PairWindow<TT, C>;
-        constexpr uint32_t kPts = kWindow;                       // 2: 8 windows + their far rows in flight per lane
-        const uint32_t safe_last = table_rows - PW::kWin - m.offset;
-        for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
-            float w[kPts][8];
-            PW pw[kPts][4];
-#pragma unroll
-            for (uint32_t k = 0; k < kPts; ++k) {
-                const uint32_t b = min(b0 + k * stride, B - 1u);
-                float x[3], frac[3];
-                uint32_t pg[3];
-                src.get(b, x);
-                locate<3>(x, m.scale, frac, pg);
-                uint32_t row[8];
-                cell_corners<MODE, 3>(m, frac, pg, w[k], row);
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) pw[k][j].issue(grid, row[2 * j], row[2 * j + 1], safe_last);
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < kPts; ++k) {
-                const uint32_t b = b0 + k * stride;
-                float a[C];
-#pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) a[ch] = 0.0f;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    float va[C], vb[C];
-                    pw[k][j].finish(va, vb);
-#pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][2 * j], va[ch], a[ch]);
-#pragma unroll
-                    for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][2 * j + 1], vb[ch], a[ch]);
-                }
-                if (b < B) store_vec<FT, C>(feat + slot(b) * C, a);
-            }
-        }
-    } else {
-    // several points per thread and iteration: 32 independent gathers in flight per lane (measured on the chest step,
-    // C = 2: 1 / 2 / 4 / 8 points -> 3.28 / 2.99 / 2.81 / 2.90 ms)
-    constexpr uint32_t kPts = encode_points_per_thread(C);
-    for (uint32_t b0 = block_x * blockDim.x + threadIdx.x; b0 < B; b0 += kPts * stride) {
-        float w[kPts][8], v[kPts][8][C];
-#pragma unroll
-        for (uint32_t k = 0; k < kPts; ++k) {
-            const uint32_t b = min(b0 + k * stride, B - 1u);
-            float x[3], frac[3];
-            uint32_t pg[3];
-            src.get(b, x);
-            locate<3>(x, m.scale, frac, pg);
-            uint32_t row[8];
-            cell_corners<MODE, 3>(m, frac, pg, w[k], row);
-#pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) load_vec<TT, C>(grid + (size_t)row[c] * C, v[k][c]);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kPts; ++k) {
-            const uint32_t b = b0 + k * stride;
-            float a[C];
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ++ch) a[ch] = 0.0f;
-#pragma unroll
-            for (uint32_t c = 0; c < 8; ++c)
-#pragma unroll
-                for (uint32_t ch = 0; ch < C; ++ch) a[ch] = __fmaf_rn(w[k][c], v[k][c][ch], a[ch]);
-            if (b < B) store_vec<FT, C>(feat + slot(b) * C, a);
-        }
-    }
-    }
-    });
-    }
-}
-
 template <typename TT, typename P, uint32_t C, typename Src>
 static int run_encode(const Src &src, const void *table, const int32_t *offsets, void *feat, uint32_t B, const naf_render_cfg *cfg, hipStream_t s,
                       uint32_t lv_begin = 0u, uint32_t lv_end = ~0u, uint32_t chunk = 0u) {
-    // [lv_begin, lv_end): the levels to encode (all by default; a level-parallel rank encodes the levels it owns, naf_levels_encode).
-    // `feat` is indexed by the ABSOLUTE level: level l of point b sits at (l * B + b) * C -- unless `chunk` != 0 (a level range only):
-    // then the output is [b / chunk][l - lv_begin][b % chunk][C], see encode_kernel.
-    using FT = typename P::feat_t;
-    lv_end = std::min(lv_end, cfg->L);
-    const uint32_t nl = lv_end - lv_begin;
-    constexpr bool kCanWindow = PairWindow<TT, C>::kUsable;
-    // x-neighbour corners through ONE 16-byte window per pair (fewer L1 accesses: what small batches are bound by) or through two
-    // gathers with four points per lane in flight (more misses outstanding: what large batches are bound by).  Measured
-    // (encode_kernel, window / two gathers, ms): 1 024 rays 0.067 / 0.088, 2 048: 0.115 / 0.117, 4 096: 0.216 / 0.211, 16 384:
-    // 0.777 / 0.753, 65 536: 3.00 / 2.89; T = 2^22 fp16 (foot) 6.20 / 5.85; fp32 tables (a window covers only the mask-1 pairs, but
-    // the L1 is the tighter resource there) 0.908 / 1.008 at 16 384 rays.  NAF_CFG_ENCODE_TWO_GATHERS / _WINDOWS force one form.
-    bool window = kCanWindow && (B < 600000u || sizeof(typename TT::store_t) == 4u);
-    if ((cfg->flags & NAF_CFG_ENCODE_WINDOWS) != 0u) window = kCanWindow;
-    if ((cfg->flags & NAF_CFG_ENCODE_TWO_GATHERS) != 0u) window = false;
-    auto kern = encode_kernel<TT, FT, C, Src, 0u>;
-    if constexpr (kCanWindow) { if (window) kern = encode_kernel<TT, FT, C, Src, 2u>; }
-    const uint32_t kPts = window ? 2u : encode_points_per_thread(C);
-    if (per_level_launches(cfg) && chunk == 0u) {
-        static const char *const names[32] = NAF_LEVEL_NAMES("encode_kernel_L");
-        for (uint32_t l = lv_begin; l < lv_end; ++l) {
-            ProfScope prof_(level_name(names, l), s);
-            hipLaunchKernelGGL(kern, dim3(hash_grid_x((B + kPts - 1u) / kPts), 1), dim3(256), 0, s, src,
-                               (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, l, 0u, 1u, cfg->L, 0u, 0u);
-        }
-        return check_launch("encode_kernel");
-    }
-    const uint32_t gx = hash_grid_x((B + kPts - 1u) / kPts);
-    const bool interleaved = (cfg->flags & NAF_CFG_LEVELS_INTERLEAVED) != 0u && gx <= 65535u;
-    // XCD groups (order 4 + log2 G; see encode_kernel): a level is pulled through 8 / G L2s instead of eight.  Measured on the chest
-    // step (encode_kernel, ms; level-major / G = 2 / 4 / 8): 256 rays 0.036 / 0.029 / 0.023 / 0.023, 512: 0.047 / 0.038 / 0.034 / 0.037,
-    // 1 024: 0.068 / 0.061 / 0.061 / 0.067, 2 048: 0.111 / 0.108 / 0.110 / 0.121, 4 096: 0.202 / 0.202 / 0.207 / 0.230, 16 384:
-    // 0.735 / 0.753 / 0.791 / 0.884 -- four groups below 160 000 points, two below 500 000, level-major above.
-    // NAF_CFG_ENCODE_GROUPS_2 / _4 / both (= 8) force G, NAF_CFG_ENCODE_LEVEL_MAJOR forces none.
-    uint32_t log2g = B < 160000u ? 2u : B < 500000u ? 1u : 0u;
-    if ((cfg->flags & (NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4)) != 0u)
-        log2g = ((cfg->flags & NAF_CFG_ENCODE_GROUPS_2) != 0u ? 1u : 0u) + ((cfg->flags & NAF_CFG_ENCODE_GROUPS_4) != 0u ? 2u : 0u);
-    if ((cfg->flags & NAF_CFG_ENCODE_LEVEL_MAJOR) != 0u) log2g = 0u;
-    while (log2g != 0u && nl % (1u << log2g) != 0u) --log2g;                 // a level range: as many groups as divide it
-    const bool grouped = !interleaved && log2g != 0u && (nl >= 8u || nl != cfg->L);
-    const uint32_t order = interleaved ? 1u : grouped ? 4u + log2g : 0u;
-    const dim3 grid = interleaved ? dim3(nl, gx) : grouped ? dim3((nl * gx + 7u) / 8u * 8u) : dim3(gx, nl);
-    { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
-                       (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, cfg->H, lv_begin, order, nl, cfg->L, gx, chunk); }
-    return check_launch("encode_kernel");
+    // encode_kernel.h; features are written in the MLP's operand precision (P::feat_t), whatever the table stores
+    return launch_encode<TT, typename P::feat_t, C, Src>(src, table, offsets, feat, B, cfg->H, cfg->L, cfg->flags, s, lv_begin, lv_end, chunk);
 }
 
 template <typename P, uint32_t C, typename Src>
@@ -1165,11 +946,6 @@ static int run_mlp_backward(const void *feat, const float *mlp, const SrcRays &s
     return run_mlp_grad_reduce(slabs, grid, grad_mlp, loss_out, with_loss, madam, gmax_bits, ex, s);
 }
 
-// Workgroups a reducer launch over `nl` levels splits each bucket's tiles between: 1 when buckets x levels give every CU a
-// workgroup (one owner per row, sums formed in a fixed order: the table gradient is bit-reproducible -- this covers the four-level
-// buckets of a data-parallel step, 64 x 4 = 256), more (with per-row fp32 atomics at the end, whose order is not fixed) only when a
-// pass holds fewer than four levels' worth of buckets.
-static uint32_t reducer_split(uint32_t NB, uint32_t nl) { return NB * nl >= 256u ? 1u : std::max(1u, std::min(16u, 1024u / (NB * nl))); }
 // The Adam tail (naf_render_train_adam) needs every reducer launch of the step unsplit, the binned scatter and level-major launches.
 static bool adam_tail_possible(const naf_render_cfg *cfg, const Workspace &w) {
     if (!w.binned || per_level_launches(cfg)) return false;
@@ -1218,7 +994,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
         ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
         const uint32_t spare = job.slabs != nullptr ? kSlabReduceBlocks : 0u;
         hipLaunchKernelGGL(bin, dim3(plan.n_tiles + spare, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const typename FT::store_t *)dfeat,
-                           offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job);
+                           offsets, grad_table, (Rec *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job, B, 1u);
         job = SlabReduce{};
         return check_launch("scatter_bin_kernel");
     };
@@ -1265,14 +1041,17 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
     const uint32_t threads = big ? 2u * NT : NT;
     const bool many = plan.n_tiles >= (big ? 768u : 1536u);
     const uint32_t LV = many ? kLvMany : kLvFew;
-    auto bin = big ? (many ? scatter_bin2_kernel<2u * NT, kLvMany> : scatter_bin2_kernel<2u * NT, kLvFew>)
-                   : (many ? scatter_bin2_kernel<NT, kLvMany> : scatter_bin2_kernel<NT, kLvFew>);
+    // 64 buckets per level (every table up to 2^19 rows per level): the variant whose waves scan the bucket counters themselves
+    const bool nb64 = plan.log2_nb == 6u;
+    auto bin = big ? (many ? scatter_bin2_kernel<2u * NT, kLvMany, 0u> : scatter_bin2_kernel<2u * NT, kLvFew, 0u>)
+                   : nb64 ? (many ? scatter_bin2_kernel<NT, kLvMany, 6u> : scatter_bin2_kernel<NT, kLvFew, 6u>)
+                          : (many ? scatter_bin2_kernel<NT, kLvMany, 0u> : scatter_bin2_kernel<NT, kLvFew, 0u>);
     const bool fast = adam != nullptr && adam->lp != nullptr;        // tables with a 16-bit shadow: adam_math.h
     auto red = adam == nullptr ? scatter_reduce2_kernel<false, false> : fast ? scatter_reduce2_kernel<true, true> : scatter_reduce2_kernel<true, false>;
     const AdamTail tail = adam != nullptr ? *adam : AdamTail{};
     const uint32_t NB = 1u << plan.log2_nb;
     const uint32_t red_lds = plan.max_local_rows * 2u * 8u;
-    const uint32_t bin_lds = (2u * NB + 4u) * 4u + plan.slots * (uint32_t)sizeof(PairFx) + (plan.slots / 2u) * 12u;      // + the side list
+    const uint32_t bin_lds = (3u * NB + 4u) * 4u + (plan.slots + 1u) * (uint32_t)sizeof(PairFx) + side_list_capacity(plan.slots) * 12u;      // counters, staging, side list
     if (int rc = raise_lds_limit(red, red_lds, "binned scatter: cannot raise dynamic LDS limit (reduce)")) return rc;
     if (int rc = raise_lds_limit(bin, bin_lds, "binned scatter: cannot raise dynamic LDS limit (bin)")) return rc;
     static const char *const bin_names[32] = NAF_LEVEL_NAMES("scatter_bin_kernel_L");
@@ -1293,7 +1072,7 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
         const uint32_t n_split = reducer_split(NB, nl);
         if (adam != nullptr && n_split != 1u) return fail(NAF_ERR_LAUNCH, "binned scatter: the Adam tail needs unsplit reducer launches");
         hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const PairFx *)w.regions, w.counts, offsets,
-                           grad_table, w.gmax, l0, ly0, plan, tail);
+                           grad_table, w.gmax, l0, ly0, cfg->H, plan, tail);
         return check_launch("scatter_reduce_kernel");
     };
     if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {

@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(NT, NT >= 512u ? 4 : 2)       // 512 threads: 
 scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const int32_t *__restrict__ offsets,
                    float *__restrict__ grad_table, Rec *__restrict__ blocks, uint32_t *__restrict__ runs,
                    uint32_t *__restrict__ overflow, uint32_t B, uint32_t H, uint32_t level_base, uint32_t n_levels,
-                   BinPlan plan, SlabReduce slab_job) {
+                   BinPlan plan, SlabReduce slab_job, uint32_t grad_stride_l, uint32_t grad_stride_b) {
+    // the C gradients of (level l, point b) sit at grad + (l * grad_stride_l + b * grad_stride_b) * C: (B, 1) for [L, B, C], (1, L) for [B, L, C]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Spare workgroups behind the tiles (first launch of a training step): the reduction of the MLP backward's weight-gradient
     // slabs -- nothing in this kernel needs its results, the reducer that follows does (the gradient maximum), so it runs beside the
@@ -202,7 +203,8 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
     float g[PTS][C];
     if (blockIdx.y * LV < n_levels) {
 #pragma unroll
-        for (uint32_t q = 0; q < PTS; ++q) raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + bp[q]) * C, graw[q]);
+        for (uint32_t q = 0; q < PTS; ++q)
+            raw_load<FT, C>(grad + ((size_t)(level_base + blockIdx.y * LV) * grad_stride_l + (size_t)bp[q] * grad_stride_b) * C, graw[q]);
     }
 #pragma unroll
     for (uint32_t q = 0; q < PTS; ++q) raw_unpack<FT, C>(graw[q], g[q]);
@@ -293,7 +295,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         // would sit out their whole round trip.  This way the stores drain behind the next level's arithmetic.
         if (it + 1u < LV && ly + 1u < n_levels) {
 #pragma unroll
-            for (uint32_t q = 0; q < PTS; ++q) raw_load<FT, C>(grad + ((size_t)(level + 1u) * B + bp[q]) * C, graw[q]);
+            for (uint32_t q = 0; q < PTS; ++q) raw_load<FT, C>(grad + ((size_t)(level + 1u) * grad_stride_l + (size_t)bp[q] * grad_stride_b) * C, graw[q]);
         }
         lds_barrier();
 #pragma unroll

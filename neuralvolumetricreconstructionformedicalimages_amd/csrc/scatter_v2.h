@@ -29,6 +29,7 @@
 // replaces the fp64 route (26 significant bits below the step's largest gradient: two more than the fp32 mantissa the atomic path sums with).
 #pragma once
 
+#include "hash_kernels.h"
 #include "scatter_binned.h"
 
 namespace naf {
@@ -48,9 +49,8 @@ __device__ __forceinline__ int fixed_shift2(uint32_t gmax_bits) {
 }
 
 // rows a bucket of a level with T rows owns: [bucket << sh, (bucket + 1) << sh)
-__host__ __device__ __forceinline__ uint32_t bucket_shift(uint32_t T, uint32_t log2_nb) {
-    uint32_t bits = 0u;
-    while (bits < 32u && (1ull << bits) < (unsigned long long)T) ++bits;      // ceil(log2 T); scalar, once per level
+__device__ __forceinline__ uint32_t bucket_shift(uint32_t T, uint32_t log2_nb) {
+    const uint32_t bits = T > 1u ? 32u - (uint32_t)__builtin_clz(T - 1u) : 0u;      // ceil(log2 T); scalar, once per level
     return bits > log2_nb ? bits - log2_nb : 0u;
 }
 
@@ -78,12 +78,56 @@ __device__ __attribute__((noinline)) void spill_record(float *__restrict__ gg, u
     }
 }
 
+// entries of pass 1's side list (second-corner singles of a tile and level; what does not fit goes to the table with atomics): a
+// merged run of two or more points emits four of them, i.e. at most two per point = half of the tile's pair count, 3/8 of the
+// block's slots (which are 11/8 of the pair count)
+__host__ __device__ constexpr uint32_t side_list_capacity(uint32_t slots) { return slots / 8u * 3u; }
+
+// ---- row <-> (bucket, local row) of a level -----------------------------------------------------------------------------
+// A level's rows are dealt to the NB buckets in chunks of 2^s consecutive rows: bucket = (row >> s) & (NB - 1), local row = the
+// remaining high bits : the low s bits.  s = sh (the top-bit form of the header: one chunk per bucket) on hashed and wrapped-dense
+// levels; the small dense levels (T_l = (R + 1)^3 < 2^log2T, never a power of two: top bits would leave up to half of the buckets
+// without rows and send a ray's cells to two or three of the rest) keep 64-row chunks -- their records are merged singles anyway.
+struct RowMap {
+    uint32_t s, smask, hs;            // chunk shift, 2^s - 1, s + log2 NB
+    __device__ __forceinline__ uint32_t bucket(uint32_t row, uint32_t nb_mask) const { return (row >> s) & nb_mask; }
+    __device__ __forceinline__ uint32_t local(uint32_t row) const { return (row & smask) | ((row >> hs) << s); }
+    __device__ __forceinline__ uint32_t row(uint32_t bucket, uint32_t local) const { return ((local >> s) << hs) | (bucket << s) | (local & smask); }
+};
+__device__ __forceinline__ RowMap make_row_map(uint32_t mode, uint32_t T, uint32_t log2_nb) {
+    const uint32_t sh = bucket_shift(T, log2_nb);
+    RowMap m;
+    m.s = mode == kDenseNoMod ? min(sh, 6u) : sh;
+    m.smask = (1u << m.s) - 1u;
+    m.hs = m.s + log2_nb;
+    return m;
+}
+
+// wave-wide inclusive prefix sum on DPP (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
-// LDS: hist[NB] | start[NB] | total (4 dwords) | staging[slots] records | side list [slots / 2] x 12 bytes.  One workgroup = one tile of NT x 2 points x LV levels.
-// Per level: (A) every thread builds the records of its points in registers; ds_add_rtn_u32 on the bucket's counter returns the
-// record's rank, (B) wave 0 turns the counters into exclusive offsets and publishes (start, length) of every run, (C) every record
-// goes to staging[start[bucket] + rank], (D) the dense, bucket-sorted block leaves for HBM as whole 128-byte lines.
-template <uint32_t NT, uint32_t LV>
+// LDS: hist[2][NB] | start[NB] | misc (4 dwords) | staging[slots + 1] records | side list [3/8 slots] x 12 bytes.
+// One workgroup = one tile of NT x 2 points x LV levels.  Per level: (A) every thread builds the records of its points in registers;
+// ds_add_rtn_u32 on the bucket's counter returns the record's rank; barrier; (B) the counters become exclusive offsets -- with 64
+// buckets EVERY wave does that for itself (one LDS read + a DPP prefix sum, a bucket per lane; ds_bpermute then hands a record its
+// bucket's offset), so there is no serial section and no second barrier; with more buckets wave 0 scans into start[] behind one more
+// barrier; (C) every record goes to staging[offset + rank]; barrier; (D) the dense, bucket-sorted block leaves for HBM as whole
+// 128-byte lines.  Counters and the side list's length are double-buffered by level parity: the copy the NEXT level will use is
+// cleared between this level's two barriers.
+// What the round-4 counters said about the first form of this kernel (profiles/round4_scatter_counters.md): its waves were parked
+// 57 % of the time and issued as many scalar as vector instructions -- exec-mask juggling around per-record conditions.  So the
+// common level (not merged, every lane emits: lanes past the end of the batch carry a zero gradient and their records add nothing)
+// has a body of its own without a single per-lane branch; a record that finds its block full is noticed by ONE vote per level.
+template <uint32_t NT, uint32_t LV, uint32_t kLog2NB>            // kLog2NB: 6 = the 64-bucket plan, 0 = as the plan says (T >= 2^20)
 __global__ void __launch_bounds__(NT, 4)                       // 512 threads: two workgroups per CU; 1024: one -- 16 waves either way
 scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
                     PairFx *__restrict__ blocks, uint32_t *__restrict__ runs, uint32_t *__restrict__ overflow, uint32_t B, uint32_t H,
@@ -95,19 +139,20 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         return;
     }
     constexpr uint32_t PTS = 2u;
-    const uint32_t NB = 1u << plan.log2_nb, SLOTS = plan.slots;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *start = hist + NB;
-    uint32_t *total_p = start + NB;                                // [0] records of the level, [1] length of the side list
-    uint2 *staging = reinterpret_cast<uint2 *>(total_p + 4);       // [SLOTS]
+    constexpr bool kWaveScan = kLog2NB == 6u;
+    const uint32_t log2_nb = kLog2NB != 0u ? kLog2NB : plan.log2_nb, NB = 1u << log2_nb, nb_mask = NB - 1u, SLOTS = plan.slots;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);           // [2][NB]
+    uint32_t *start = hist + 2u * NB;                              // [NB]   (only without kWaveScan)
+    uint32_t *misc = start + NB;                                   // [0] records of the level, [1], [2] length of the side list (by level parity)
+    uint2 *staging = reinterpret_cast<uint2 *>(misc + 4);          // [SLOTS + 1]: slot SLOTS swallows the records of a full block
     // Second-corner singles do not travel in registers (eight more record slots per thread for something that happens to 2^-13 of
     // the pairs on the hashed levels would cost the kernel its occupancy): phase A appends them to a side list in LDS
     // { bucket << 16 | rank, head, pay } and phase C places them together with everything else.
-    const uint32_t side_cap = SLOTS / 2u;
-    uint32_t *side = reinterpret_cast<uint32_t *>(staging + SLOTS);   // [side_cap][3]
+    const uint32_t side_cap = side_list_capacity(SLOTS);
+    uint32_t *side = reinterpret_cast<uint32_t *>(staging + SLOTS + 1u);      // [side_cap][3]
     const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t i = threadIdx.x; i < NB; i += NT) hist[i] = 0u;
-    if (threadIdx.x == 0u) total_p[1] = 0u;
+    for (uint32_t i = threadIdx.x; i < 2u * NB; i += NT) hist[i] = 0u;
+    if (threadIdx.x < 4u) misc[threadIdx.x] = 0u;
 
     float x[PTS][3];
     uint32_t bp[PTS];
@@ -131,29 +176,31 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
     for (uint32_t it = 0; it < LV; ++it) {
         const uint32_t ly = blockIdx.y * LV + it;
         if (ly >= n_levels) break;                                   // uniform
-        const uint32_t level = level_base + ly;
+        const uint32_t level = level_base + ly, cur = it & 1u;
+        uint32_t *hist_c = hist + cur * NB, *side_n = misc + 1u + cur;
         const LevelMeta m = make_level_meta<3>(offsets, level, H);
         float *__restrict__ gg = grad_table + (size_t)m.offset * 2u;
-        const uint32_t sh = bucket_shift(m.size, plan.log2_nb), lmask = (1u << sh) - 1u;
+        const RowMap map = make_row_map(m.mode, m.size, log2_nb);
         // merge runs of equal cells inside the wave where cells are at least two sample spacings wide (an invariant of the level, see
-        // scatter_binned.h: fewer than 2^16 cells per axis, so that the cell key packs); their records are singles
+        // scatter_binned.h: fewer than 2^16 cells per axis, so that the cell key packs)
         const bool merging = m.scale * spacing < 0.5f && m.scale < 65535.0f;
+        const bool fast = !merging && bucket_shift(m.size, 0u) <= map.hs;             // not merged, one chunk per bucket: row >> hs == 0
 
-        // ---- A: records (registers) + rank inside the bucket ------------------------------------------------------------------
         uint32_t head[PTS][4], pay[PTS][4], bkt[PTS][4], rank[PTS][4];
         bool on[PTS];
         // a second corner that travels as a record of its own: counted and ranked like every record, kept in the side list
         auto emit_b = [&](uint32_t rb, uint32_t p) __attribute__((always_inline)) {
-            const uint32_t i = atomicAdd(&total_p[1], 1u);
+            const uint32_t i = atomicAdd(side_n, 1u);
             if (i < side_cap) {
-                const uint32_t b = rb >> sh, r = atomicAdd(&hist[b], 1u);
-                side[3u * i] = (b << 16) | r; side[3u * i + 1u] = rb & lmask; side[3u * i + 2u] = p;
+                const uint32_t b = map.bucket(rb, nb_mask), r = atomicAdd(&hist_c[b], 1u);
+                side[3u * i] = (b << 16) | r; side[3u * i + 1u] = map.local(rb); side[3u * i + 2u] = p;
             } else {                                                 // a tile of nothing but singles with a full list: see spill_record
                 spill_record(gg, rb, 0u, p);
                 ++n_overflow;
                 ++n_overflow_level;
             }
         };
+        // ---- A: records (registers) + rank inside the bucket ------------------------------------------------------------------
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) {
             float g[2];
@@ -207,10 +254,14 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
             const float fx = frac[0], gx = 1.0f - frac[0];
             const uint32_t fxq = (uint32_t)(fx * 32768.0f);          // < 32768: fx < 1
             on[q] = valid[q];
+            // Merged levels: all eight corner contributions are summed over each run of equal cells with a segmented inclusive scan on
+            // DPP row shifts (runs cut at 16-lane rows; scatter_binned.h) and only the last lane of a run emits.  A run of ONE point
+            // (len == 0 at its last lane) still is one product times one fraction: it travels as pair records like everywhere else;
+            // a truly merged run emits eight singles.  Either way a point costs at most four record slots and two side-list
+            // entries, whatever the geometry.
+            float va[4][2], vb[4][2];
+            bool merged_lane = false;                                // this lane closes a run of two or more points
             if (merging) {
-                // all eight corner contributions, merged over each run of equal cells with a segmented inclusive scan on DPP row
-                // shifts (runs cut at 16-lane rows; scatter_binned.h); only the last lane of a run emits, as eight singles
-                float va[4][2], vb[4][2];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
                     const float wyz = wy[k & 1u] * wz[k >> 1];
@@ -238,21 +289,18 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
                 fold(std::integral_constant<uint32_t, 4>{});
                 fold(std::integral_constant<uint32_t, 8>{});
                 on[q] = valid[q] && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    head[q][k] = ra[k] & lmask; bkt[q][k] = ra[k] >> sh; pay[q][k] = pack_bf16x2(va[k][0], va[k][1]);
-                    if (on[q]) emit_b(ra[k] ^ xm[k], pack_bf16x2(vb[k][0], vb[k][1]));
-                }
-            } else {
+                merged_lane = on[q] && len != 0u;
+            }
+            {
                 // the common case first, for every lane: a pair record per k ...
                 bool single[4], any = false;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
                     const float wyz = wy[k & 1u] * wz[k >> 1];
-                    single[k] = valid[q] && !(formed[k] && xm[k] <= lmask);
+                    single[k] = on[q] && !merged_lane && !(formed[k] && xm[k] <= map.smask);
                     any = any || single[k];
-                    bkt[q][k] = ra[k] >> sh;
-                    head[q][k] = (ra[k] & lmask) | ((uint32_t)__builtin_popcount(xm[k]) << kFxEShift) | (fxq << kFxShift);
+                    bkt[q][k] = fast ? ra[k] >> map.s : map.bucket(ra[k], nb_mask);
+                    head[q][k] = (fast ? ra[k] & map.smask : map.local(ra[k])) | ((uint32_t)__builtin_popcount(xm[k]) << kFxEShift) | (fxq << kFxShift);
                     pay[q][k] = pack_bf16x2(wyz * g[0], wyz * g[1]);
                 }
                 // ... then the lanes whose corners have different owners (2^-sh of the pairs: a wave-level branch that is almost never
@@ -263,16 +311,30 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
                         if (single[k]) {
                             const float wyz = wy[k & 1u] * wz[k >> 1];
                             const float p0 = wyz * g[0], p1 = wyz * g[1];
-                            head[q][k] = ra[k] & lmask; pay[q][k] = pack_bf16x2(p0 * gx, p1 * gx);
+                            head[q][k] &= (1u << kFxLocalBits) - 1u; pay[q][k] = pack_bf16x2(p0 * gx, p1 * gx);
                             emit_b(ra[k] ^ xm[k], pack_bf16x2(p0 * fx, p1 * fx));
                         }
                     }
                 }
             }
+            if (merging && __ballot(merged_lane) != 0ull) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                rank[q][k] = 0u;
-                if (on[q]) rank[q][k] = atomicAdd(&hist[bkt[q][k]], 1u);                       // ds_add_rtn_u32
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (merged_lane) {
+                        head[q][k] &= (1u << kFxLocalBits) - 1u; pay[q][k] = pack_bf16x2(va[k][0], va[k][1]);
+                        emit_b(ra[k] ^ xm[k], pack_bf16x2(vb[k][0], vb[k][1]));
+                    }
+                }
+            }
+            if (fast) {                                              // every lane emits (see the header): no exec juggling around the atomics
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) rank[q][k] = atomicAdd(&hist_c[bkt[q][k]], 1u);           // ds_add_rtn_u32
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    rank[q][k] = 0u;
+                    if (on[q]) rank[q][k] = atomicAdd(&hist_c[bkt[q][k]], 1u);
+                }
             }
         }
         // the next level's gradients: requested here, consumed right after the barrier and before this level's stores are issued (vmcnt
@@ -285,57 +347,105 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) asm volatile("" : "+v"(graw[q]) : : "memory");      // pin the wait here
 
-        // ---- B: counters -> exclusive offsets (wave 0: NB / 64 consecutive buckets per lane), run words, total ----------------------
+        // ---- B: counters -> exclusive offsets, run words, total ---------------------------------------------------------------------
+        // (the counters and the side-list length of the OTHER parity are what the next level uses: nobody reads them any more -- their
+        // last readers passed the previous level's second barrier -- and nobody adds to them before this level's second barrier)
         if (wave == 0u) {
-            const uint32_t per = NB >> 6;
-            uint32_t mine = 0u;
-            for (uint32_t j = 0; j < per; ++j) mine += hist[lane * per + j];
-            uint32_t incl = mine;
-#pragma unroll
-            for (uint32_t d = 1; d < 64u; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-                if (lane >= d) incl += up;
-            }
-            uint32_t run_start = incl - mine;
-            for (uint32_t j = 0; j < per; ++j) {
-                const uint32_t b = lane * per + j, n = hist[b];
-                start[b] = run_start;
-                hist[b] = 0u;                                            // ready for the next level
-                const uint32_t start_c = min(run_start, SLOTS), n_c = min(n, SLOTS - start_c);      // what fits the block
-                runs[run_index(plan, ly, b, tile)] = start_c | (n_c << 16);
-                run_start += n;
-            }
-            if (lane == 63u) total_p[0] = incl;
+            for (uint32_t i = lane; i < NB; i += 64u) hist[(cur ^ 1u) * NB + i] = 0u;
+            if (lane == 0u) misc[1u + (cur ^ 1u)] = 0u;
         }
-        lds_barrier();
+        uint32_t excl = 0u, total = 0u;
+        if constexpr (kWaveScan) {
+            const uint32_t n = hist_c[lane];
+            const uint32_t incl = wave_inclusive_sum(n);
+            excl = incl - n;
+            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (wave == 0u) {
+                const uint32_t start_c = min(excl, SLOTS), n_c = min(n, SLOTS - start_c);      // what fits the block
+                runs[run_index(plan, ly, lane, tile)] = start_c | (n_c << 16);
+            }
+        } else {
+            if (wave == 0u) {
+                const uint32_t per = NB >> 6;
+                uint32_t mine = 0u;
+                for (uint32_t j = 0; j < per; ++j) mine += hist_c[lane * per + j];
+                const uint32_t incl = wave_inclusive_sum(mine);
+                uint32_t run_start = incl - mine;
+                for (uint32_t j = 0; j < per; ++j) {
+                    const uint32_t b = lane * per + j, n = hist_c[b];
+                    start[b] = run_start;
+                    const uint32_t start_c = min(run_start, SLOTS), n_c = min(n, SLOTS - start_c);
+                    runs[run_index(plan, ly, b, tile)] = start_c | (n_c << 16);
+                    run_start += n;
+                }
+                if (lane == 63u) misc[0] = incl;
+            }
+            lds_barrier();
+            total = misc[0];
+        }
 
         // ---- C: placement -------------------------------------------------------------------------------------------------
-        auto place = [&](uint32_t b, uint32_t r, uint32_t h, uint32_t p) __attribute__((always_inline)) {
-            const uint32_t pos = start[b] + r;
-            if (pos < SLOTS) staging[pos] = make_uint2(h, p);
-            else {
-                spill_record(gg, (b << sh) | (h & lmask), h, p);
-                ++n_overflow;
-                ++n_overflow_level;
-            }
+        auto offset_of = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {
+            if constexpr (kWaveScan) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b << 2), (int)excl);
+            else return start[b];
         };
+        bool over = false;
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) {
-            if (on[q]) {
+            if (fast) {
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) place(bkt[q][k], rank[q][k], head[q][k], pay[q][k]);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t pos = offset_of(bkt[q][k]) + rank[q][k];
+                    over = over || pos >= SLOTS;
+                    staging[min(pos, SLOTS)] = make_uint2(head[q][k], pay[q][k]);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t pos = offset_of(bkt[q][k]) + rank[q][k];          // every lane takes part in the bpermute
+                    if (on[q]) {
+                        over = over || pos >= SLOTS;
+                        staging[min(pos, SLOTS)] = make_uint2(head[q][k], pay[q][k]);
+                    }
+                }
             }
         }
         {
-            const uint32_t n_side = min(total_p[1], side_cap);
-            for (uint32_t i = threadIdx.x; i < n_side; i += NT) place(side[3u * i] >> 16, side[3u * i] & 0xffffu, side[3u * i + 1u], side[3u * i + 2u]);
+            const uint32_t n_side = min(*side_n, side_cap);
+            for (uint32_t i0 = 0; i0 < n_side; i0 += NT) {                            // uniform trip count: bpermute needs the whole wave
+                const uint32_t i = i0 + threadIdx.x;
+                const bool live = i < n_side;
+                const uint32_t w0 = live ? side[3u * i] : 0u;
+                const uint32_t pos = offset_of(w0 >> 16) + (w0 & 0xffffu);
+                if (live) {
+                    const uint32_t h = side[3u * i + 1u], p = side[3u * i + 2u];
+                    if (pos < SLOTS) staging[pos] = make_uint2(h, p);
+                    else {
+                        spill_record(gg, map.row(w0 >> 16, h), h, p);
+                        ++n_overflow;
+                        ++n_overflow_level;
+                    }
+                }
+            }
+        }
+        if (__ballot(over) != 0ull) {                                     // a full block (see spill_record): one vote per level
+#pragma unroll
+            for (uint32_t q = 0; q < PTS; ++q)
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t pos = offset_of(bkt[q][k]) + rank[q][k];
+                    if ((fast || on[q]) && pos >= SLOTS) {
+                        spill_record(gg, map.row(bkt[q][k], head[q][k] & ((1u << kFxLocalBits) - 1u)), head[q][k], pay[q][k]);
+                        ++n_overflow;
+                        ++n_overflow_level;
+                    }
+                }
         }
         lds_barrier();
 
         // ---- D: the dense block leaves as whole 128-byte lines (16 bytes per lane; stale slots past the end are harmless) -----
         {
-            if (threadIdx.x == 0u) total_p[1] = 0u;                      // every wave has read the side list's length (barrier above)
-            const uint32_t n_rec = min(total_p[0], SLOTS);
+            const uint32_t n_rec = min(total, SLOTS);
             const uint32_t n_chunk = min(((n_rec * 8u + 127u) >> 7) << 3, (SLOTS * 8u) >> 4);
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 *__restrict__ dst = reinterpret_cast<u32x4 *>(blocks + block_index(plan, ly, tile));
@@ -349,8 +459,8 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
             if (lane == 0u) atomicAdd(overflow + 1u + level, n_overflow_level);
             n_overflow_level = 0u;
         }
-        // no barrier here: the next level touches only `hist` (cleared in B) before its first barrier and writes `start` / the staging
-        // block after it -- every wave has finished this copy before it arrives there
+        // no barrier here: the next level adds to the counters of the other parity and writes the staging block only behind ITS first
+        // barrier -- every wave has finished this copy before it arrives there
     }
     if (__ballot(n_overflow != 0u)) {
 #pragma unroll
@@ -380,13 +490,15 @@ template <bool kAdam, bool kFast>
 __global__ void __launch_bounds__(1024)
 scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
                        float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, uint32_t ly_begin,
-                       BinPlan plan, AdamTail adam) {
+                       uint32_t H, BinPlan plan, AdamTail adam) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
-    const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
-    const uint32_t sh = bucket_shift(T, plan.log2_nb), row_begin = bucket << sh;
-    if (row_begin >= T) return;                                  // a level smaller than its share of buckets (dense coarse levels): no rows, no records
-    const uint32_t rows = min(T - row_begin, 1u << sh);
+    const LevelMeta lm = make_level_meta<3>(offsets, level, H);
+    const uint32_t off = lm.offset, T = lm.size;
+    const RowMap map = make_row_map(lm.mode, T, plan.log2_nb);
+    if ((bucket << map.s) >= T) return;                          // a level with fewer chunks than buckets: no rows, no records
+    // local rows this bucket may own: whole chunks of 2^s rows (the last chunk of the level may be cut short: row < T is checked per row)
+    const uint32_t rows_local = ((T + ((1u << map.hs) - 1u)) >> map.hs) << map.s;
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift2(gbits);
     const bool poison = fixed_nonfinite(gbits);
@@ -398,17 +510,21 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
     struct __attribute__((packed, aligned(4))) Quad { float x, y, z, w; };              // level offsets may be odd: 8-byte aligned only
     constexpr uint32_t kPreQ = kAdam ? 4u : 0u;                  // quads (two rows x two channels) prefetched per thread
     Quad preq_p[kPreQ ? kPreQ : 1u], preq_m[kPreQ ? kPreQ : 1u], preq_v[kPreQ ? kPreQ : 1u];
-    const uint32_t n_quads = (rows + 1u) >> 1;
-    const size_t e0 = ((size_t)off + row_begin) * 2u;            // first table element of the bucket
+    // quad q = local rows 2q, 2q + 1 = two CONSECUTIVE table rows when chunks hold at least two rows (s >= 1) and both exist
+    const uint32_t n_quads = (rows_local + 1u) >> 1;
+    auto quad_row = [&](uint32_t q) { return map.row(bucket, 2u * q); };
+    auto quad_full = [&](uint32_t row0) { return map.s != 0u && row0 + 1u < T; };
     if constexpr (kPreQ != 0u) {
 #pragma unroll
         for (uint32_t k = 0; k < kPreQ; ++k) {
             const uint32_t q = threadIdx.x + k * T_;
+            const uint32_t row0 = quad_row(q);
             preq_p[k] = preq_m[k] = preq_v[k] = Quad{0.0f, 0.0f, 0.0f, 0.0f};
-            if (2u * q + 1u < rows) {
-                preq_p[k] = *reinterpret_cast<const Quad *>(adam.param + e0 + 4u * q);
-                preq_m[k] = *reinterpret_cast<const Quad *>(adam.m + e0 + 4u * q);
-                preq_v[k] = *reinterpret_cast<const Quad *>(adam.v + e0 + 4u * q);
+            if (q < n_quads && quad_full(row0)) {
+                const size_t e = ((size_t)off + row0) * 2u;
+                preq_p[k] = *reinterpret_cast<const Quad *>(adam.param + e);
+                preq_m[k] = *reinterpret_cast<const Quad *>(adam.m + e);
+                preq_v[k] = *reinterpret_cast<const Quad *>(adam.v + e);
             }
         }
     }
@@ -437,8 +553,10 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
         const float a0 = p0 * scale - b0, a1 = p1 * scale - b1;                          // exact: p * 2^shift * (1 - f_x)
         atomicAdd(&acc0[la], (unsigned long long)(long long)cvt_rpi(a0));                // ds_add_u64
         atomicAdd(&acc1[la], (unsigned long long)(long long)cvt_rpi(a1));
-        atomicAdd(&acc0[lb], (unsigned long long)(long long)cvt_rpi(b0));
-        atomicAdd(&acc1[lb], (unsigned long long)(long long)cvt_rpi(b1));
+        if (e != 0u) {                                                                   // singles (the merged levels' records) add nothing there
+            atomicAdd(&acc0[lb], (unsigned long long)(long long)cvt_rpi(b0));
+            atomicAdd(&acc1[lb], (unsigned long long)(long long)cvt_rpi(b1));
+        }
     };
     constexpr uint32_t kGroup = 8u, kTail = 32u;
     if (plan.log2_w < 6u) {
@@ -518,7 +636,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
     }
     __syncthreads();
 
-    float *__restrict__ gg = grad_table + e0;
+    float *__restrict__ gg = grad_table + (size_t)off * 2u;
     const float nan = __builtin_nanf("");
     // fixed point -> fp32 of the four sums of a quad (rows 2q, 2q + 1 x channels 0, 1).  Sums that fit 32 bits -- nearly all -- convert
     // with v_cvt_f32_i32 + v_ldexp_f32: one rounding of the same exact value as the fp64 route; chosen per wave (scatter_binned.h).
@@ -541,10 +659,10 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
         // A level whose tiles overflowed their blocks has contributions in the gradient table already (atomics of pass 1): they are
         // added and cleared here.
         const bool spilled = adam.overflow[1u + level] != 0u;
-        float *__restrict__ pp = adam.param + e0, *__restrict__ pm = adam.m + e0, *__restrict__ pv = adam.v + e0;
-        auto store_lp = [&](uint32_t el, uint32_t count, const float (&p)[4]) {      // 16-bit shadow of `count` elements from local element `el`
+        float *__restrict__ pp = adam.param + (size_t)off * 2u, *__restrict__ pm = adam.m + (size_t)off * 2u, *__restrict__ pv = adam.v + (size_t)off * 2u;
+        auto store_lp = [&](size_t el, uint32_t count, const float (&p)[4]) {       // 16-bit shadow of `count` elements from level element `el`
             if (adam.lp == nullptr) return;
-            uint16_t *lp = reinterpret_cast<uint16_t *>(adam.lp) + e0 + el;
+            uint16_t *lp = reinterpret_cast<uint16_t *>(adam.lp) + (size_t)off * 2u + el;
             uint32_t lo, hi;
             if (adam.lp_dtype == kAdamLpF16) {
                 const _Float16 h0 = (_Float16)p[0], h1 = (_Float16)p[1], h2 = (_Float16)p[2], h3 = (_Float16)p[3];
@@ -558,49 +676,57 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
             if (count == 4u) *reinterpret_cast<Half4 *>(lp) = Half4{lo, hi};
             else *reinterpret_cast<uint32_t *>(lp) = lo;
         };
+        auto one_row = [&](uint32_t row, float g0, float g1) {                       // two elements of a row that has no partner in its quad
+            const size_t el = (size_t)row * 2u;
+            float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float g[2] = {g0, g1};
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                float gc = g[c];
+                if (spilled) {
+                    const float extra = gg[el + c];
+                    if (extra != 0.0f) { gc = extra + gc; gg[el + c] = 0.0f; }
+                }
+                float m = pm[el + c], v = pv[el + c];
+                p[c] = pp[el + c];
+                adam_one<kFast>(p[c], m, v, gc, adam.a);
+                pp[el + c] = p[c]; pm[el + c] = m; pv[el + c] = v;
+            }
+            store_lp(el, 2u, p);
+        };
         auto finish = [&](uint32_t q, bool prefetched, const Quad &p4, const Quad &m4, const Quad &v4) {
             if (q >= n_quads) return;
             float g[4];
             sums(q, g);
-            if (2u * q + 1u < rows) {
+            const uint32_t row0 = quad_row(q);
+            if (quad_full(row0)) {
+                const size_t el = (size_t)row0 * 2u;
                 Quad P = p4, M = m4, V = v4;
                 if (!prefetched) {
-                    P = *reinterpret_cast<const Quad *>(pp + 4u * q);
-                    M = *reinterpret_cast<const Quad *>(pm + 4u * q);
-                    V = *reinterpret_cast<const Quad *>(pv + 4u * q);
+                    P = *reinterpret_cast<const Quad *>(pp + el);
+                    M = *reinterpret_cast<const Quad *>(pm + el);
+                    V = *reinterpret_cast<const Quad *>(pv + el);
                 }
                 if (spilled) {
-                    const Quad extra = *reinterpret_cast<const Quad *>(gg + 4u * q);
+                    const Quad extra = *reinterpret_cast<const Quad *>(gg + el);
                     const float x[4] = {extra.x, extra.y, extra.z, extra.w};
                     bool any = false;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; ++j)
                         if (x[j] != 0.0f) { g[j] = x[j] + g[j]; any = true; }          // the order of the separate route: table += sum
-                    if (any) *reinterpret_cast<Quad *>(gg + 4u * q) = Quad{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (any) *reinterpret_cast<Quad *>(gg + el) = Quad{0.0f, 0.0f, 0.0f, 0.0f};
                 }
                 float p[4] = {P.x, P.y, P.z, P.w}, m[4] = {M.x, M.y, M.z, M.w}, v[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; ++j) adam_one<kFast>(p[j], m[j], v[j], g[j], adam.a);
-                *reinterpret_cast<Quad *>(pp + 4u * q) = Quad{p[0], p[1], p[2], p[3]};
-                *reinterpret_cast<Quad *>(pm + 4u * q) = Quad{m[0], m[1], m[2], m[3]};
-                *reinterpret_cast<Quad *>(pv + 4u * q) = Quad{v[0], v[1], v[2], v[3]};
-                store_lp(4u * q, 4u, p);
-            } else {                                          // the bucket's last row when its row count is odd: two elements
-                float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (uint32_t c = 0; c < 2; ++c) {
-                    const uint32_t el = 4u * q + c;
-                    float gc = g[c];
-                    if (spilled) {
-                        const float extra = gg[el];
-                        if (extra != 0.0f) { gc = extra + gc; gg[el] = 0.0f; }
-                    }
-                    float m = pm[el], v = pv[el];
-                    p[c] = pp[el];
-                    adam_one<kFast>(p[c], m, v, gc, adam.a);
-                    pp[el] = p[c]; pm[el] = m; pv[el] = v;
-                }
-                store_lp(4u * q, 2u, p);
+                *reinterpret_cast<Quad *>(pp + el) = Quad{p[0], p[1], p[2], p[3]};
+                *reinterpret_cast<Quad *>(pm + el) = Quad{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<Quad *>(pv + el) = Quad{v[0], v[1], v[2], v[3]};
+                store_lp(el, 4u, p);
+            } else {                                          // the level's last row when its count is odd, or one-row chunks (tiny tables)
+                if (row0 < T) one_row(row0, g[0], g[1]);
+                const uint32_t row1 = map.row(bucket, 2u * q + 1u);
+                if (2u * q + 1u < rows_local && row1 < T) one_row(row1, g[2], g[3]);
             }
         };
 #pragma unroll
@@ -613,15 +739,22 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
         for (uint32_t q = threadIdx.x; q < n_quads; q += T_) {
             float g[4];
             sums(q, g);
-            const uint32_t count = 2u * q + 1u < rows ? 4u : 2u;
-            if (gridDim.z == 1u && count == 4u) {
-                Quad *dst = reinterpret_cast<Quad *>(gg + 4u * q);
+            const uint32_t row0 = quad_row(q);
+            if (gridDim.z == 1u && quad_full(row0)) {
+                Quad *dst = reinterpret_cast<Quad *>(gg + (size_t)row0 * 2u);
                 const Quad old = *dst;
                 *dst = Quad{old.x + g[0], old.y + g[1], old.z + g[2], old.w + g[3]};
             } else {
-                for (uint32_t j = 0; j < count; ++j) {
-                    if (gridDim.z == 1u) gg[4u * q + j] += g[j];
-                    else atomicAdd(gg + 4u * q + j, g[j]);
+#pragma unroll
+                for (uint32_t r = 0; r < 2; ++r) {
+                    const uint32_t row = map.row(bucket, 2u * q + r);
+                    if (2u * q + r < rows_local && row < T) {
+#pragma unroll
+                        for (uint32_t c = 0; c < 2; ++c) {
+                            if (gridDim.z == 1u) gg[(size_t)row * 2u + c] += g[2u * r + c];
+                            else atomicAdd(gg + (size_t)row * 2u + c, g[2u * r + c]);
+                        }
+                    }
                 }
             }
         }

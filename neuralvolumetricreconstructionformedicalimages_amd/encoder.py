@@ -2,7 +2,7 @@
 src/encoder/__init__.py over the HIP kernels in libnaf_hip.so.
 
 Same names, arguments and error behaviour as the reference:
-  * `hash_encode(inputs, embeddings, offsets, base_resolution, calc_grad_inputs)`  (hashgrid.py:10-74)
+  * `hash_encode(inputs, embeddings, offsets, base_resolution, calc_grad_inputs[, log2_hashmap_size])`  (hashgrid.py:10-74)
   * `HashEncoder(input_dim, num_levels, level_dim, base_resolution, log2_hashmap_size)` with `.output_dim`,
     `.embeddings`, `.offsets`, `forward(inputs, size=1)`                               (hashgrid.py:77-137)
   * `get_encoder(encoding, ...)`                                                       (src/encoder/__init__.py:5-24)
@@ -34,8 +34,10 @@ def level_offsets(input_dim, num_levels, base_resolution, log2_hashmap_size):
 
 class _hash_encode(Function):
     @staticmethod
-    def forward(ctx, inputs, embeddings, offsets, base_resolution, calc_grad_inputs=False):
+    def forward(ctx, inputs, embeddings, offsets, base_resolution, calc_grad_inputs=False, log2_hashmap_size=None):
         # inputs [B, D] float in [0,1]; embeddings [sO, C]; offsets [L+1] int32; returns [B, L*C]
+        # log2_hashmap_size (an extension of the reference signature, hashgrid.py:13): when given, the backward pass may use the
+        # binned scatter with a scratch workspace (naf_hash_encode_backward_ws) instead of one global atomic per corner and channel
         # calc_grad_inputs: False / True (exact input gradient) / _abi.GRAD_INPUTS_REFERENCE (the reference's dy_dx,
         # level scale missing, `nd > gd` dimension pick -- only for comparing against reference runs)
         if torch.is_autocast_enabled():                   # reference: custom_fwd(cast_inputs=torch.half)
@@ -57,6 +59,7 @@ class _hash_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, H]
         ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.log2_hashmap_size = log2_hashmap_size
         return outputs
 
     @staticmethod
@@ -67,12 +70,24 @@ class _hash_encode(Function):
         grad = grad.contiguous().to(embeddings.dtype)
         grad_embeddings = torch.zeros(embeddings.shape, device=embeddings.device, dtype=torch.float32)
         grad_inputs = torch.zeros_like(inputs) if calc else None
-        _abi.check(_abi.lib().naf_hash_encode_backward(
-            _abi.ptr(grad), _abi.ptr(inputs), _abi.ptr(embeddings), _abi.ptr(offsets), _abi.ptr(grad_embeddings),
-            B, D, C, L, H, int(calc), _abi.ptr(dy_dx), _abi.ptr(grad_inputs), _abi.dtype_code(embeddings.dtype),
-            _abi.LAYOUT_BLC, _abi.stream_ptr()), "hash_encode_backward")
+        dtc = _abi.dtype_code(embeddings.dtype)
+        need = 0
+        if ctx.log2_hashmap_size is not None:
+            need = int(_abi.lib().naf_hash_encode_workspace_bytes(B, D, C, L, int(ctx.log2_hashmap_size), dtc))
+        if need:
+            from . import fused
+            ws = fused._grow(inputs.device, need)           # the per-device scratch buffer of the fused calls (stream-ordered reuse)
+            _abi.check(_abi.lib().naf_hash_encode_backward_ws(
+                _abi.ptr(grad), _abi.ptr(inputs), _abi.ptr(embeddings), _abi.ptr(offsets), _abi.ptr(grad_embeddings),
+                B, D, C, L, H, int(calc), _abi.ptr(dy_dx), _abi.ptr(grad_inputs), dtc, _abi.LAYOUT_BLC, int(ctx.log2_hashmap_size),
+                _abi.ptr(ws), ws.numel(), _abi.stream_ptr()), "hash_encode_backward_ws")
+        else:
+            _abi.check(_abi.lib().naf_hash_encode_backward(
+                _abi.ptr(grad), _abi.ptr(inputs), _abi.ptr(embeddings), _abi.ptr(offsets), _abi.ptr(grad_embeddings),
+                B, D, C, L, H, int(calc), _abi.ptr(dy_dx), _abi.ptr(grad_inputs), dtc, _abi.LAYOUT_BLC, _abi.stream_ptr()),
+                "hash_encode_backward")
         grad_embeddings = grad_embeddings.to(embeddings.dtype)
-        return (grad_inputs if calc else None), grad_embeddings, None, None, None
+        return (grad_inputs if calc else None), grad_embeddings, None, None, None, None
 
 
 hash_encode = _hash_encode.apply
@@ -150,7 +165,7 @@ class HashEncoder(nn.Module):
         calc = inputs.requires_grad
         if calc and self.reference_compat:
             calc = _abi.GRAD_INPUTS_REFERENCE
-        outputs = hash_encode(inputs, self.embeddings, self._device_offsets(inputs.device), self.base_resolution, calc)
+        outputs = hash_encode(inputs, self.embeddings, self._device_offsets(inputs.device), self.base_resolution, calc, self.log2_hashmap_size)
         return outputs.view(prefix_shape + [self.output_dim])
 
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_abi.SIGNATURES) == _declared()
-    assert _abi.lib().naf_abi_version() == 3
+    assert _abi.lib().naf_abi_version() == 4
     assert _abi.lib().naf_last_error() is not None
 
 
@@ -88,7 +88,7 @@ def test_argument_validation_needs_no_gpu():
     from neuralvolumetricreconstructionformedicalimages_amd import fused
     n = 1 << 30
     assert lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n) == 64 * n + 256
-    assert lib.naf_render_workspace_bytes(ctypes.byref(cfg), n) > 3 * lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n)
+    assert lib.naf_render_workspace_bytes(ctypes.byref(cfg), n) > 2.5 * lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n)    # (172 B per point with the 8-byte scatter records of round 4)
     cfg.flags = _abi.CFG_FORWARD_FUSED
     assert lib.naf_forward_workspace_bytes(ctypes.byref(cfg), n) == 256
     assert fused.FORWARD_WORKSPACE_CAP <= 8 << 30

@@ -95,6 +95,58 @@ def test_backward_fp32(layout):
     np.testing.assert_allclose(ge.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("layout,dtype,C,log2T", [("blc", "fp32", 2, 19), ("lbc", "fp32", 2, 19), ("blc", "bf16", 2, 19), ("lbc", "fp16", 4, 16),
+                                                  ("blc", "fp32", 4, 21)])
+def test_backward_with_workspace_equals_the_atomic_route(layout, dtype, C, log2T):
+    """naf_hash_encode_backward_ws (the binned two-pass scatter of the training path behind the operator's signature: caller's
+    workspace, `+=` into grad_embeddings) against naf_hash_encode_backward (the reference scheme, one atomic per corner and channel) on
+    the same inputs: 1e-5 of the largest sum for fp32 gradients (both accumulate the same fp32 products; only the order differs),
+    3e-3 where the records carry 16-bit gradients.  Coordinates include points outside [0, 1] and samples of rays (runs of equal
+    cells on the coarse levels); the caller's content of grad_embeddings is kept; a NULL workspace falls back to the atomic route."""
+    _abi, encoder, c_oracle, hr = _mods()
+    L, H = 16, 16
+    offs = torch.from_numpy(hr.level_offsets(L, H, log2T, 3)).cuda()
+    g0 = torch.Generator().manual_seed(11)
+    n_rays, S = 96, 192                                            # 18 432 points: above the 2^13 floor of the binned scatter
+    o = torch.rand(n_rays, 1, 3, generator=g0)
+    d = torch.rand(n_rays, 1, 3, generator=g0) - 0.5
+    x = (o + d * torch.linspace(0, 1.2, S).view(1, S, 1)).reshape(-1, 3).contiguous()      # some samples leave the unit cube
+    B = x.shape[0]
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.randn(B, L * C, generator=g0).to(tdt)
+    lay = _abi.LAYOUT_BLC
+    gd = g.cuda()
+    if layout == "lbc":
+        gd = gd.view(B, L, C).permute(1, 0, 2).contiguous()
+        lay = _abi.LAYOUT_LBC
+    xd = x.cuda()
+    dtc = _abi.dtype_code(tdt)
+    need = int(_abi.lib().naf_hash_encode_workspace_bytes(B, 3, C, L, log2T, dtc))
+    assert need > 0
+    assert int(_abi.lib().naf_hash_encode_workspace_bytes(4096, 3, C, L, log2T, dtc)) == 0      # small batches: the atomic route
+    assert int(_abi.lib().naf_hash_encode_workspace_bytes(B, 2, C, L, log2T, dtc)) == 0         # D = 2 likewise
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    n_rows = int(offs[-1])
+    base = torch.rand(n_rows, C, device="cuda")
+    out = {}
+    for route in ("atomic", "ws", "ws_null"):
+        ge = base.clone()
+        if route == "atomic":
+            _abi.check(_abi.lib().naf_hash_encode_backward(_abi.ptr(gd), _abi.ptr(xd), None, _abi.ptr(offs), _abi.ptr(ge), B, 3, C, L, H,
+                                                           0, None, None, dtc, lay, _abi.stream_ptr()))
+        else:
+            w = ws if route == "ws" else None
+            _abi.check(_abi.lib().naf_hash_encode_backward_ws(_abi.ptr(gd), _abi.ptr(xd), None, _abi.ptr(offs), _abi.ptr(ge), B, 3, C, L, H,
+                                                              0, None, None, dtc, lay, log2T, _abi.ptr(w), 0 if w is None else w.numel(),
+                                                              _abi.stream_ptr()))
+        torch.cuda.synchronize()
+        out[route] = (ge - base).double().cpu().numpy()
+    scale = np.abs(out["atomic"]).max()
+    tol = 1e-5 if dtype == "fp32" else 3e-3
+    assert np.abs(out["ws"] - out["atomic"]).max() <= tol * scale
+    assert np.abs(out["ws_null"] - out["atomic"]).max() <= 2e-5 * scale
+
+
 def test_backward_accumulates_and_input_grad():
     _abi, encoder, c_oracle, hr = _mods()
     offs = hr.level_offsets(5, 4, 10, 3)
