@@ -573,7 +573,8 @@ def main():
         tb, fb = {"bf16": (2, 2), "fp32": (4, 4)}[args.precision]
         kernels = {k: {"launches": c, "total_ms": ms, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         mfma_peak = 2500.0 if args.precision == "bf16" else 157.3      # TFLOP/s dense, MI355X_MICROARCH.md
-        rec_bytes = 12 if args.precision == "bf16" else 20             # pair record of the binned scatter (scatter_binned.h)
+        # pair record of the binned scatter: 8 bytes in bf16 mode (scatter_v2.h; 12 with the round-3 kernels, --cfg-flags 2048), 20 in fp32 mode
+        rec_bytes = (12 if args.cfg_flags & 2048 else 8) if args.precision == "bf16" else 20
         fused_adam = engine.fuse_table_adam and engine._dp is None
         # Algorithmic bytes / flops of ONE launch of each kernel.  encode: SURVEY 8(d)'s hash-forward figure.
         # The gradient scatter is two kernels here, each priced on what it must move: bin reads the feature gradients and writes

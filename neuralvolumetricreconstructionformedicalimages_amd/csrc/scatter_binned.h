@@ -251,12 +251,32 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
             // face of the volume its x pairs are unpaired on every level from 2 on, and 8 records per clone would fill the
             // block and push the tile's real records out to atomics
             on[q] = valid[q];
+            bool keyed = valid[q];                                       // takes part in the cell runs of a merged level
+            if constexpr (!Src::kInRange) {
+                // Coordinates nobody range-checked (the stand-alone operator): outside [0, 1] the reference's weights are whatever its
+                // arithmetic gives (|w| > 1, NaN), which the fixed-point reducer -- scaled for |w g| <= max |g| -- cannot take.  Such a
+                // point goes to the table the reference's way, with atomics (hashencoder.cu:266-269), and emits no record.
+                bool inside = true;
+#pragma unroll
+                for (uint32_t d = 0; d < 3; ++d) inside = inside && x[q][d] >= 0.0f && x[q][d] <= 1.0f;
+                if (valid[q] && !inside) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 8; ++c)
+#pragma unroll
+                        for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(gg + (size_t)row[c] * C + ch, val[c][ch]);
+                }
+                on[q] = keyed = valid[q] && inside;
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c)
+#pragma unroll
+                    for (uint32_t ch = 0; ch < C; ++ch) val[c][ch] = keyed ? val[c][ch] : 0.0f;
+            }
             if (merging) {
                 // Merge each run of equal cells with a segmented inclusive scan; only the last lane of a run emits.  Runs
                 // are cut at 16-lane rows: the scan then moves its operands with DPP row shifts (a modifier of the VALU
                 // instruction) instead of 6 x 16 trips through the LDS crossbar (ds_bpermute).
                 // (padding lanes get a cell key of their own -- bit 31 of c_hi -- so that they never share a run with real points)
-                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2] | (valid[q] ? 0u : 0x80000000u);    // merging levels have < 2^16 cells per axis
+                const uint32_t c_lo = pg[0] | (pg[1] << 16), c_hi = pg[2] | (keyed ? 0u : 0x80000000u);    // merging levels have < 2^16 cells per axis
                 const uint32_t p_lo = dpp_row_shr<1>(c_lo), p_hi = dpp_row_shr<1>(c_hi);
                 const uint64_t heads = __ballot((lane & 15u) == 0u || c_lo != p_lo || c_hi != p_hi);
                 const uint32_t start = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
@@ -273,7 +293,7 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
                 fold(std::integral_constant<uint32_t, 2>{});
                 fold(std::integral_constant<uint32_t, 4>{});
                 fold(std::integral_constant<uint32_t, 8>{});
-                on[q] = valid[q] && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
+                on[q] = keyed && (lane == 63u || ((heads >> (lane + 1u)) & 1ull));
             }
             // x-neighbour corners (2k, 2k+1) travel together when their rows share a 64-row block; otherwise (1.6 % of the
             // pairs) the record keeps both value halves with mask 0 and phase C splits it into two single records

@@ -110,7 +110,11 @@ def test_backward_with_workspace_equals_the_atomic_route(layout, dtype, C, log2T
     n_rays, S = 96, 192                                            # 18 432 points: above the 2^13 floor of the binned scatter
     o = torch.rand(n_rays, 1, 3, generator=g0)
     d = torch.rand(n_rays, 1, 3, generator=g0) - 0.5
-    x = (o + d * torch.linspace(0, 1.2, S).view(1, S, 1)).reshape(-1, 3).contiguous()      # some samples leave the unit cube
+    # some samples leave the unit cube -- on its high side only: there the reference's weights stay in [0, 1] (a NEGATIVE coordinate
+    # makes them -1e5 per dimension on the fine levels, and sums of such terms differ between two runs of the SAME atomic kernel)
+    x = (o + d * torch.linspace(0, 1.2, S).view(1, S, 1)).clamp(min=0.0).reshape(-1, 3).contiguous()
+    inside = ((x >= 0) & (x <= 1)).all(dim=1)
+    assert 0.02 < float((~inside).float().mean()) < 0.5
     B = x.shape[0]
     tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     g = torch.randn(B, L * C, generator=g0).to(tdt)
@@ -141,10 +145,22 @@ def test_backward_with_workspace_equals_the_atomic_route(layout, dtype, C, log2T
                                                               _abi.stream_ptr()))
         torch.cuda.synchronize()
         out[route] = (ge - base).double().cpu().numpy()
-    scale = np.abs(out["atomic"]).max()
+    # Points outside [0, 1] take the atomic route inside the binned scatter too (its fixed-point sums are scaled for weights in [0, 1]);
+    # the comparison is relative per element, with an absolute floor taken from the in-range points alone.
+    ge_in = torch.zeros(n_rows, C, device="cuda")
+    keep = inside.cuda()
+    g_in = (gd if layout == "blc" else gd.permute(1, 0, 2).reshape(B, L * C)).clone()
+    g_in[~keep] = 0
+    g_in = g_in if layout == "blc" else g_in.view(B, L, C).permute(1, 0, 2).contiguous()
+    x_in = xd.clone()
+    x_in[~keep] = 0.5
+    _abi.check(_abi.lib().naf_hash_encode_backward(_abi.ptr(g_in), _abi.ptr(x_in), None, _abi.ptr(offs), _abi.ptr(ge_in), B, 3, C, L, H,
+                                                   0, None, None, dtc, lay, _abi.stream_ptr()))
+    torch.cuda.synchronize()
+    scale = float(ge_in.abs().max())
     tol = 1e-5 if dtype == "fp32" else 3e-3
-    assert np.abs(out["ws"] - out["atomic"]).max() <= tol * scale
-    assert np.abs(out["ws_null"] - out["atomic"]).max() <= 2e-5 * scale
+    np.testing.assert_allclose(out["ws"], out["atomic"], rtol=max(tol, 2e-5), atol=tol * scale)
+    np.testing.assert_allclose(out["ws_null"], out["atomic"], rtol=2e-5, atol=2e-5 * scale)
 
 
 def test_backward_accumulates_and_input_grad():

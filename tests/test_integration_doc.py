@@ -48,3 +48,14 @@ def test_documented_ctypes_backend_matches_the_drop_in_module():
     want.backward(grad)
     ref = enc.embeddings.grad
     assert float((grad_embeddings - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+    # a training-sized batch (above 2^13 points): the documented backend lends the library a workspace and gets the binned scatter
+    B2 = 20000
+    x2 = torch.rand(B2, D, device="cuda")
+    grad2 = torch.randn(B2, L * C, device="cuda")
+    ge2 = torch.zeros_like(emb)
+    _backend.hash_encode_backward(grad2, x2, emb, offsets, ge2, B2, D, C, L, H, False, dy_dx, torch.zeros_like(x2))
+    enc.zero_grad()
+    hash_encode(x2, enc.embeddings, offsets, H, False).backward(grad2)       # no log2_hashmap_size: the atomic route of the module
+    ref2 = enc.embeddings.grad
+    assert float((ge2 - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())

@@ -11,7 +11,7 @@ PART=${1:-A}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 if [ "$PART" = A ]; then
-COMMON="--cpu-seconds 0 --sub-records 0 --psnr-seconds 0"
+COMMON="--cpu-seconds 0 --sub-records 0 --psnr-seconds 0 --full-schedule 0"
 # the bench's default workload (chest_50.yaml's own step: 1 024 rays) and the throughput end of the batch curve (65 536 rays)
 for R in 1024 65536; do
   if [ $R = 1024 ]; then ARGS="--steps 200 --warmup 20 --rays $R $COMMON"; PMC="--steps 50 --warmup 10 --rays $R $COMMON"; else ARGS="--steps 10 --warmup 2 --rays $R $COMMON"; PMC="--steps 3 --warmup 1 --rays $R $COMMON"; fi
@@ -30,9 +30,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/sqb -o sqb -- python3 bench.py --steps 2 --warmup 1 --rays 65536 $COMMON > $OUT/bench_sqb.json 2> $OUT/sqb.err
 echo sq done
 # the counter passes are in: derive profiles/pmc_traffic.json now, so that the default line below carries `roofline.traffic`
-NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3} > $OUT/install_a.log 2>&1
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round4} > $OUT/install_a.log 2>&1
 cp gpurun_out/profiles_staged/pmc_traffic.json profiles/pmc_traffic.json
-timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout -k 10 700 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo default done
 for r in 128 256 512 1024 2048 4096 16384 65536 262144 1048576; do
   timeout -k 10 300 python bench.py --steps 20 --warmup 5 --rays $r $COMMON >> $OUT/batch_sweep.jsonl 2>> $OUT/batch_sweep.err
@@ -40,11 +40,11 @@ done
 echo sweep done
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --rays 16384 --precision fp32 $COMMON > $OUT/bench_fp32_16384.json 2> $OUT/fp32.err
 timeout -k 10 300 python bench.py --per-level --steps 5 --warmup 2 --rays 16384 $COMMON > $OUT/bench_per_level_16384.json 2> $OUT/per_level.err
-timeout -k 10 300 python bench.py --force-dp --steps 200 --warmup 20 --cpu-seconds 0 --psnr-seconds 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
+timeout -k 10 300 python bench.py --force-dp --steps 200 --warmup 20 --cpu-seconds 0 --psnr-seconds 0 --full-schedule 0 > $OUT/bench_force_dp.json 2> $OUT/force_dp.err
 # the encoder with all levels of a point tile in flight at once (what a single fused gather+MLP kernel would do to the caches)
 timeout -k 10 300 python bench.py --interleaved-levels --rays 65536 --steps 10 --warmup 3 $COMMON > $OUT/bench_interleaved.json 2> $OUT/interleaved.err
 echo modes done
-NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3}
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round4}
 rm -rf $OUT/stats_1024 $OUT/stats_65536 $OUT/fetch_1024 $OUT/fetch_65536 $OUT/write_1024 $OUT/write_65536 $OUT/mfma $OUT/sqa $OUT/sqb
 ls gpurun_out/profiles_staged
 exit 0
@@ -69,7 +69,7 @@ timeout -k 10 200 python tools/levels_emulate.py --ranks 8 --precision fp32 2>> 
 for r in 1024 4096; do      # foot_50 shapes
   timeout -k 10 300 python tools/levels_emulate.py --ranks 8 --rays $r --log2T 22 --samples 320 --table fp16 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
 done
-timeout -k 10 200 python bench.py --force-dp --dp-mode levels --steps 1000 --psnr-seconds 0 --cpu-seconds 0 --sub-records 0 2> $OUT/levels_one_rank.err | tail -n 1 > $OUT/bench_level_parallel_one_rank.json
+timeout -k 10 200 python bench.py --force-dp --dp-mode levels --steps 1000 --psnr-seconds 0 --cpu-seconds 0 --sub-records 0 --full-schedule 0 2> $OUT/levels_one_rank.err | tail -n 1 > $OUT/bench_level_parallel_one_rank.json
 echo level-parallel emulation done
 # T = 2^22 (foot_50 shapes, the table is larger than every cache level below the Infinity Cache): HBM bytes fetched by the
 # encoder of the FUSED forward, quoted against the north star's 60 % bar in DESIGN.md section 4.1
@@ -85,6 +85,6 @@ timeout -k 10 300 python tools/train_chest.py --rays 1024 --steps 20000 --eval-e
 timeout -k 10 400 python tools/psnr_race.py --configs 256:2e-3,512:2e-3,512:4e-3,1024:1e-3,1024:2e-3,1024:4e-3,1024:8e-3,2048:4e-3,4096:4e-3,16384:4e-3,65536:8e-3 --max-train-s 10 --out $OUT/psnr_race_grid.jsonl > $OUT/race.log 2>&1
 echo all done
 # summarise on the box and keep only the summaries (the kernel traces alone exceed what gpurun copies back)
-NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round3}
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round4}
 rm -rf $OUT/t22_fp16 $OUT/t22_fp32
 ls gpurun_out/profiles_staged

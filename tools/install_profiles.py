@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
 DST = os.environ.get("NAF_PROFILES_DST", os.path.join(REPO, "profiles"))      # the GPU box stages into gpurun_out/ (no 64 MiB of traces)
 os.makedirs(DST, exist_ok=True)
-TAG = sys.argv[1] if len(sys.argv) > 1 else "round3"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "round4"
 
 
 def copy(src, dst):
@@ -49,7 +49,8 @@ from neuralvolumetricreconstructionformedicalimages_amd.build import source_fing
 # profiles/round3_cache_counters.md shows the calibration: exact for scattered single-sector gathers, half for whole lines --
 # every kernel of this step streams whole lines except the encoder, whose fetches are 1 % of its traffic at T = 2^19).
 # Keys are the names bench.py's profiler uses (naf_profile_collect): the 16-point MFMA kernels report under the generic names.
-ALIAS = {"mlp16_forward_kernel": "mlp_forward_kernel", "mlp16_backward_kernel": "mlp_backward_kernel"}
+ALIAS = {"mlp16_forward_kernel": "mlp_forward_kernel", "mlp16_backward_kernel": "mlp_backward_kernel",
+         "scatter_bin2_kernel": "scatter_bin_kernel", "scatter_reduce2_kernel": "scatter_reduce_kernel"}      # scatter_v2.h
 by_rays = {}
 for R in (1024, 65536):
     fetch = glob.glob(os.path.join(SRC, f"fetch_{R}", "**", "*counter_collection.csv"), recursive=True)
@@ -120,7 +121,7 @@ def counters(*files):
 
 sq = counters("sqa/sqa_counter_collection.csv", "sqb/sqb_counter_collection.csv")
 mf = counters("mfma/mfma_counter_collection.csv")
-kernels = ("encode_kernel", "mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "draw_scan_rays_kernel", "adam_kernel")
+kernels = ("encode_kernel", "mlp16_forward_kernel", "mlp16_backward_kernel", "mlp_forward_kernel", "mlp_backward_kernel", "scatter_bin_kernel", "scatter_reduce_kernel", "scatter_bin2_kernel", "scatter_reduce2_kernel", "draw_scan_rays_kernel", "adam_kernel")
 out = ["# Counter evidence per kernel (MI355X, chest_50 bf16, 65 536 rays/step = 12.58 M points; tools/collect_profiles.sh)", "",
        "## Dynamic instruction mix", "",
        "`rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- python3 bench.py --steps 2 --warmup 1 --rays 65536 --cpu-seconds 0`,",
