@@ -154,7 +154,7 @@ static int launch_backward_ws(const void *grad, const float *inputs, const int32
                            (Rec *)w.regions, w.counts, w.overflow, B, H, l0, nl, plan, SlabReduce{}, sl, sb); }
         if (int rc = check_launch("scatter_bin_kernel")) return rc;
         { ProfScope prof_("scatter_reduce_kernel", s); hipLaunchKernelGGL(red, dim3(NB, nl, reducer_split(NB, nl)), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets, gtab,
-                           w.gmax, l0, 0u, plan, AdamTail{}); }
+                           w.gmax, l0, 0u, H, plan, AdamTail{}); }
         if (int rc = check_launch("scatter_reduce_kernel")) return rc;
     }
     (void)cfg;

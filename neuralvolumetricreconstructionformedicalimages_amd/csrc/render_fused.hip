@@ -844,7 +844,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12 | NAF_CFG_ENCODE_NO_WARM)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1006,7 +1006,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
         const uint32_t n_split = reducer_split(NB, nl);
         if (adam != nullptr && n_split != 1u) return fail(NAF_ERR_LAUNCH, "binned scatter: the Adam tail needs unsplit reducer launches");
         hipLaunchKernelGGL(red, dim3(NB, nl, n_split), dim3(1024), red_lds, s, (const Rec *)w.regions, w.counts, offsets,
-                           grad_table, w.gmax, l0, ly0, plan, tail);
+                           grad_table, w.gmax, l0, ly0, cfg->H, plan, tail);
         return check_launch("scatter_reduce_kernel");
     };
     if (buckets != nullptr && !per_level && plan.levels_per_pass >= cfg->L && lv_begin == 0u && lv_end == cfg->L) {

@@ -133,15 +133,35 @@ __device__ __forceinline__ long long to_fixed(float v, double scale) {
 }
 
 // ---- row <-> (bucket, local row) -------------------------------------------------------------------------------------
-// bucket = bits [6, 6 + log2 NB), local = (row >> (6 + log2 NB)) << 6 | (row & 63)
-__device__ __forceinline__ uint32_t bucket_of(uint32_t row, uint32_t log2_nb) { return (row >> 6) & ((1u << log2_nb) - 1u); }
-__device__ __forceinline__ uint32_t local_of(uint32_t row, uint32_t log2_nb) { return ((row >> (6u + log2_nb)) << 6) | (row & 63u); }
-__device__ __forceinline__ uint32_t row_of(uint32_t bucket, uint32_t local, uint32_t log2_nb) {
-    return ((local >> 6) << (6u + log2_nb)) | (bucket << 6) | (local & 63u);
+// (round 4: the chunked map below replaced "bucket = bits [6, 6 + log2 NB)" in these kernels too.  With 64-row chunks on EVERY level
+// 1.6 % of the x pairs were unpaired -- and ALL pairs of a ray that runs parallel to an axis with its x cell at 63 mod 64: on such
+// projections single tiles of the fp32 parity mode (512-point tiles = 2.7 rays) filled their blocks and spilled records to float
+// atomics, whose order is not fixed -- two runs of the same fp32 training differed from the step that drew projection 25 of 50 on,
+// tools/determinism_probe.py.)
+// rows a bucket of a level with T rows owns: [bucket << sh, (bucket + 1) << sh)
+__device__ __forceinline__ uint32_t bucket_shift(uint32_t T, uint32_t log2_nb) {
+    const uint32_t bits = T > 1u ? 32u - (uint32_t)__builtin_clz(T - 1u) : 0u;      // ceil(log2 T); scalar, once per level
+    return bits > log2_nb ? bits - log2_nb : 0u;
 }
-// local rows a bucket of a level with T rows can hold: whole 64-row blocks
-__device__ __forceinline__ uint32_t local_rows(uint32_t T, uint32_t log2_nb) {
-    return ((T + (64u << log2_nb) - 1u) >> (6u + log2_nb)) << 6;
+
+// ---- row <-> (bucket, local row) of a level -----------------------------------------------------------------------------
+// A level's rows are dealt to the NB buckets in chunks of 2^s consecutive rows: bucket = (row >> s) & (NB - 1), local row = the
+// remaining high bits : the low s bits.  s = sh (the top-bit form of the header: one chunk per bucket) on hashed and wrapped-dense
+// levels; the small dense levels (T_l = (R + 1)^3 < 2^log2T, never a power of two: top bits would leave up to half of the buckets
+// without rows and send a ray's cells to two or three of the rest) keep 64-row chunks -- their records are merged singles anyway.
+struct RowMap {
+    uint32_t s, smask, hs;            // chunk shift, 2^s - 1, s + log2 NB
+    __device__ __forceinline__ uint32_t bucket(uint32_t row, uint32_t nb_mask) const { return (row >> s) & nb_mask; }
+    __device__ __forceinline__ uint32_t local(uint32_t row) const { return (row & smask) | ((row >> hs) << s); }
+    __device__ __forceinline__ uint32_t row(uint32_t bucket, uint32_t local) const { return ((local >> s) << hs) | (bucket << s) | (local & smask); }
+};
+__device__ __forceinline__ RowMap make_row_map(uint32_t mode, uint32_t T, uint32_t log2_nb) {
+    const uint32_t sh = bucket_shift(T, log2_nb);
+    RowMap m;
+    m.s = max(1u, mode == kDenseNoMod ? min(sh, 6u) : sh);      // at least two rows per chunk: the reducers finish rows in pairs (16-byte quads)
+    m.smask = (1u << m.s) - 1u;
+    m.hs = m.s + log2_nb;
+    return m;
 }
 
 // runs: [level slot][bucket][tile] = start | length << 16 (one coalesced load per 64 tiles in pass 2);
@@ -222,6 +242,8 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
         // (fewer than 2^16 cells per axis), not of ray 0's spacing -- a degenerate first ray (spacing 0) must not switch merging on
         // for the fine levels, whose keys would alias.
         const bool merging = m.scale * spacing < 0.75f && m.scale < 65535.0f;
+        const RowMap map = make_row_map(m.mode, m.size, plan.log2_nb);
+        const uint32_t nb_mask = NB - 1u;
 
         // ---- A: records of the thread's points (registers), histogram -------------------------------------------------
         Rec rec[PTS][4];                                             // the four x-neighbour pairs of a cell
@@ -300,13 +322,13 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 const uint32_t ra = row[2 * k], rb = row[2 * k + 1], mask = ra ^ rb;
-                const bool paired = mask < 64u;
-                rec[q][k].set(local_of(ra, plan.log2_nb) | (paired ? mask << 16 : 0u), val[2 * k], val[2 * k + 1]);
-                bkt[q][k] = bucket_of(ra, plan.log2_nb);
+                const bool paired = mask <= map.smask;                      // both rows in one chunk of the bucket
+                rec[q][k].set(map.local(ra) | (paired ? mask << 16 : 0u), val[2 * k], val[2 * k + 1]);
+                bkt[q][k] = map.bucket(ra, nb_mask);
                 lone[q][k] = paired ? kNoRow : rb;
                 if (on[q]) {
                     atomicAdd(&hist[bkt[q][k]], 1u);
-                    if (!paired) atomicAdd(&hist[bucket_of(rb, plan.log2_nb)], 1u);
+                    if (!paired) atomicAdd(&hist[map.bucket(rb, nb_mask)], 1u);
                 }
             }
         }
@@ -379,18 +401,18 @@ scatter_bin_kernel(Src src, const typename FT::store_t *__restrict__ grad, const
             for (uint32_t k = 0; k < 4; ++k) {
                 const Rec &r = rec[q][k];
                 const uint32_t la = r.w[0] & 0xffffu;
-                const uint32_t row_a = row_of(bkt[q][k], la, plan.log2_nb);
+                const uint32_t row_a = map.row(bkt[q][k], la);
                 if (lone[q][k] == kNoRow) {
-                    place(bkt[q][k], r.w, row_a, row_of(bkt[q][k], la ^ (r.w[0] >> 16), plan.log2_nb), r);
+                    place(bkt[q][k], r.w, row_a, map.row(bkt[q][k], la ^ (r.w[0] >> 16)), r);
                 } else {                                                  // two single records: first corner, second corner
                     Rec a, b2;
                     float va[C], vb[C], zero[C];
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ++ch) { va[ch] = r.value(0, ch); vb[ch] = r.value(1, ch); zero[ch] = 0.0f; }
                     a.set(la, va, zero);
-                    b2.set(local_of(lone[q][k], plan.log2_nb), vb, zero);
+                    b2.set(map.local(lone[q][k]), vb, zero);
                     place(bkt[q][k], a.w, row_a, row_a, a);
-                    place(bucket_of(lone[q][k], plan.log2_nb), b2.w, lone[q][k], lone[q][k], b2);
+                    place(map.bucket(lone[q][k], nb_mask), b2.w, lone[q][k], lone[q][k], b2);
                 }
             }
         }
@@ -439,7 +461,7 @@ template <uint32_t C, typename Rec, bool kAdam = false>
 __global__ void __launch_bounds__(1024)
 scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
                       float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base,
-                      uint32_t ly_begin, BinPlan plan, AdamTail adam) {
+                      uint32_t ly_begin, uint32_t H, BinPlan plan, AdamTail adam) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t gbits = *gmax_bits;
     const int shift = fixed_shift(gbits);
@@ -448,8 +470,12 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t T_ = blockDim.x;
     const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
-    const uint32_t off = (uint32_t)offsets[level], T = (uint32_t)offsets[level + 1] - off;
-    const uint32_t rows_local = local_rows(T, plan.log2_nb);
+    const LevelMeta lm = make_level_meta<3>(offsets, level, H);
+    const uint32_t off = lm.offset, T = lm.size;
+    const RowMap map = make_row_map(lm.mode, T, plan.log2_nb);
+    if ((bucket << map.s) >= T) return;                      // a level with fewer chunks than buckets: no rows, no records
+    // local rows this bucket may own: whole chunks of 2^s rows (row < T is checked per row)
+    const uint32_t rows_local = ((T + ((1u << map.hs) - 1u)) >> map.hs) << map.s;
     // accumulators are channel-major, acc[ch][local row]: the two 8-byte cells of a row would otherwise sit 8 bytes apart and
     // one ds_add_u64 instruction (one channel of 64 rows) could reach only every other bank pair
     const uint32_t pitch = plan.max_local_rows;
@@ -471,7 +497,7 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
     const uint32_t n_quads = rows_local * C / 4u;                            // rows_local is a multiple of 64
     // quad q holds local rows 2q, 2q + 1 (same 64-row block) = table rows row0, row0 + 1; a level with an odd row count (dense
     // levels) ends with a quad whose second row does not exist: that one row is finished element-wise by its thread in the tail
-    auto quad_row = [&](uint32_t q) { return row_of(bucket, 2u * q, plan.log2_nb); };
+    auto quad_row = [&](uint32_t q) { return map.row(bucket, 2u * q); };
     if constexpr (kPreQ != 0u) {
         const float *__restrict__ pp = adam.param + (size_t)off * C;
         const float *__restrict__ pm = adam.m + (size_t)off * C;
@@ -497,7 +523,7 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
         for (uint32_t k = 0; k < kPre; ++k) {
             const uint32_t i = threadIdx.x + k * T_;
             const uint32_t local = i / C, ch = i - local * C;
-            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            const uint32_t row = map.row(bucket, local);
             pre_p[k] = pre_m[k] = pre_v[k] = 0.0f;
             if (i < rows_local * C && row < T) {
                 const size_t e = (size_t)row * C + ch;
@@ -727,14 +753,14 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
             for (uint32_t k = 0; k < kPre; ++k) {
                 const uint32_t i = threadIdx.x + k * T_;
                 const uint32_t local = i / C, ch = i - local * C;
-                const uint32_t row = row_of(bucket, local, plan.log2_nb);
+                const uint32_t row = map.row(bucket, local);
                 if (i < rows_local * C && row < T) update(local, ch, row, pre_p[k], pre_m[k], pre_v[k]);
             }
         }
 #pragma unroll 4
         for (uint32_t i = threadIdx.x + kPre * T_; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            const uint32_t row = map.row(bucket, local);
             if (row < T) {
                 const size_t e = (size_t)row * C + ch;
                 update(local, ch, row, pp[e], pm[e], pv[e]);
@@ -773,13 +799,13 @@ scatter_reduce_kernel(const Rec *__restrict__ blocks, const uint32_t *__restrict
         } else
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            const uint32_t row = map.row(bucket, local);
             if (row < T) gg[(size_t)row * C + ch] += poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift);
         }
     } else {
         for (uint32_t i = threadIdx.x; i < rows_local * C; i += T_) {
             const uint32_t local = i / C, ch = i - local * C;
-            const uint32_t row = row_of(bucket, local, plan.log2_nb);
+            const uint32_t row = map.row(bucket, local);
             if (row < T)
                 atomicAdd(gg + (size_t)row * C + ch,
                           poison ? nan : (float)ldexp((double)(long long)acc[ch * pitch + local], -shift));   // one add per row and split

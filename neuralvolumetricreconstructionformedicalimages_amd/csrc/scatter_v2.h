@@ -48,12 +48,6 @@ __device__ __forceinline__ int fixed_shift2(uint32_t gmax_bits) {
     return s > 120 ? 120 : s;                                 // 2^shift must be an fp32 (gradients below 2^-94: their low bits are not missed)
 }
 
-// rows a bucket of a level with T rows owns: [bucket << sh, (bucket + 1) << sh)
-__device__ __forceinline__ uint32_t bucket_shift(uint32_t T, uint32_t log2_nb) {
-    const uint32_t bits = T > 1u ? 32u - (uint32_t)__builtin_clz(T - 1u) : 0u;      // ceil(log2 T); scalar, once per level
-    return bits > log2_nb ? bits - log2_nb : 0u;
-}
-
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 pk;
@@ -82,26 +76,6 @@ __device__ __attribute__((noinline)) void spill_record(float *__restrict__ gg, u
 // merged run of two or more points emits four of them, i.e. at most two per point = half of the tile's pair count, 3/8 of the
 // block's slots (which are 11/8 of the pair count)
 __host__ __device__ constexpr uint32_t side_list_capacity(uint32_t slots) { return slots / 8u * 3u; }
-
-// ---- row <-> (bucket, local row) of a level -----------------------------------------------------------------------------
-// A level's rows are dealt to the NB buckets in chunks of 2^s consecutive rows: bucket = (row >> s) & (NB - 1), local row = the
-// remaining high bits : the low s bits.  s = sh (the top-bit form of the header: one chunk per bucket) on hashed and wrapped-dense
-// levels; the small dense levels (T_l = (R + 1)^3 < 2^log2T, never a power of two: top bits would leave up to half of the buckets
-// without rows and send a ray's cells to two or three of the rest) keep 64-row chunks -- their records are merged singles anyway.
-struct RowMap {
-    uint32_t s, smask, hs;            // chunk shift, 2^s - 1, s + log2 NB
-    __device__ __forceinline__ uint32_t bucket(uint32_t row, uint32_t nb_mask) const { return (row >> s) & nb_mask; }
-    __device__ __forceinline__ uint32_t local(uint32_t row) const { return (row & smask) | ((row >> hs) << s); }
-    __device__ __forceinline__ uint32_t row(uint32_t bucket, uint32_t local) const { return ((local >> s) << hs) | (bucket << s) | (local & smask); }
-};
-__device__ __forceinline__ RowMap make_row_map(uint32_t mode, uint32_t T, uint32_t log2_nb) {
-    const uint32_t sh = bucket_shift(T, log2_nb);
-    RowMap m;
-    m.s = mode == kDenseNoMod ? min(sh, 6u) : sh;
-    m.smask = (1u << m.s) - 1u;
-    m.hs = m.s + log2_nb;
-    return m;
-}
 
 // wave-wide inclusive prefix sum on DPP (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9)
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {

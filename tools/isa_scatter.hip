@@ -8,8 +8,8 @@
 namespace naf {
 template __global__ void scatter_bin_kernel<BF16, 2, SrcRays, PairBF16<2>, 512, 2, 16>(SrcRays, const uint16_t *, const int32_t *, float *, PairBF16<2> *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce, uint32_t, uint32_t);
 template __global__ void scatter_bin_kernel<BF16, 2, SrcRays, PairBF16<2>, 512, 2, 4>(SrcRays, const uint16_t *, const int32_t *, float *, PairBF16<2> *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce, uint32_t, uint32_t);
-template __global__ void scatter_reduce_kernel<2, PairBF16<2>, true>(const PairBF16<2> *, const uint32_t *, const int32_t *, float *, const uint32_t *, uint32_t, uint32_t, BinPlan, AdamTail);
-template __global__ void scatter_reduce_kernel<2, PairBF16<2>, false>(const PairBF16<2> *, const uint32_t *, const int32_t *, float *, const uint32_t *, uint32_t, uint32_t, BinPlan, AdamTail);
+template __global__ void scatter_reduce_kernel<2, PairBF16<2>, true>(const PairBF16<2> *, const uint32_t *, const int32_t *, float *, const uint32_t *, uint32_t, uint32_t, uint32_t, BinPlan, AdamTail);
+template __global__ void scatter_reduce_kernel<2, PairBF16<2>, false>(const PairBF16<2> *, const uint32_t *, const int32_t *, float *, const uint32_t *, uint32_t, uint32_t, uint32_t, BinPlan, AdamTail);
 }
 #include "scatter_v2.h"
 namespace naf {
