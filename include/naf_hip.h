@@ -224,8 +224,6 @@ typedef struct naf_render_cfg {
                                             for 256 / 128, so that its reducer launch has 512 workgroups that each own their rows (no split
                                             launches, the Adam tail applies) -- naf_levels_scatter                                        */
 #define NAF_CFG_MIN_BUCKETS_MASK (3u << NAF_CFG_MIN_BUCKETS_SHIFT)
-#define NAF_CFG_ENCODE_NO_WARM 32768u    /* diagnostics: the encoder's workgroups do not stream their level's slice of the table into the L2
-                                            before gathering from it (small batches with XCD groups only)                              */
 #define NAF_CFG_SCATTER_PAIR12 2048u     /* diagnostics: the binned scatter of the canonical shape (two bf16 channels) keeps the 12-byte pair
                                             records and the kernels of rounds 2-3 (scatter_binned.h) instead of scatter_v2.h's 8-byte ones */
 #define NAF_CFG_TEST_TINY_BLOCKS 4096u   /* tests: the record blocks of pass 1 hold a quarter of a tile's records, so that most

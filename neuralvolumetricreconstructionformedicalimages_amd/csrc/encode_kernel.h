@@ -35,7 +35,7 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
     uint32_t g_level = 0u, g_block = 0u;
     bool g_idle = false;
     if (order >= 4u) {
-        const uint32_t log2g = (order & 15u) - 4u, G = 1u << log2g, per = 8u >> log2g, xcd = blockIdx.x & 7u;
+        const uint32_t log2g = order - 4u, G = 1u << log2g, per = 8u >> log2g, xcd = blockIdx.x & 7u;
         const uint32_t u = (blockIdx.x >> 3) * per + (xcd % per);           // piece index inside the group
         g_level = xcd / per + G * (u / tiles);
         g_block = u % tiles;
@@ -58,28 +58,10 @@ encode_kernel(Src src, const typename TT::store_t *__restrict__ table, const int
         r -= r * chunk > b ? 1u : 0u;
         return ((size_t)r * n_levels + (level - level_base)) * chunk + (b - r * chunk);
     };
-    // Small batches (XCD groups): the gathers of a level touch nearly every 64-byte sector of its slice of the table (1.5 M gathers over
-    // 32 768 sectors at the reference's batch), so each L2 that works on the level fetches the whole slice anyway -- sector by sector,
-    // at the fabric's request rate for scattered 64-byte reads (40-58 G requests/s), which is what the kernel then waits
-    // for.  The workgroups of a level on one XCD therefore stream the slice in first, each a share, with coalesced 16-byte loads (whole
-    // 128-byte lines at the streaming rate); nothing waits for them -- they only have to be in flight before the gathers ask.
-    if (order >= 4u && (order & 16u) != 0u) {
-        const uint32_t per = 8u >> ((order & 15u) - 4u);                    // XCDs of this level's group
-        const uint32_t mine = g_block / per, sharers = (tiles + per - 1u) / per;      // this workgroup among the level's on its XCD
-        const size_t slice_bytes = (size_t)m.size * C * sizeof(typename TT::store_t);
-        const size_t share = ((slice_bytes + sharers - 1u) / sharers + 15u) & ~(size_t)15u;
-        const unsigned char *p = reinterpret_cast<const unsigned char *>(grid) + (size_t)mine * share;
-        const unsigned char *end = reinterpret_cast<const unsigned char *>(grid) + (slice_bytes & ~(size_t)15u);
-        typedef uint32_t u32x4_a4w __attribute__((ext_vector_type(4), aligned(4)));
-        uint32_t sink = 0u;
-        for (size_t o = (size_t)threadIdx.x * 16u; o < share; o += 256u * 16u) {
-            if (p + o + 16u <= end) {
-                const u32x4_a4w v = *reinterpret_cast<const u32x4_a4w *>(p + o);
-                sink ^= v.x ^ v.y ^ v.z ^ v.w;
-            }
-        }
-        asm volatile("" :: "v"(sink));                                        // the loads must be issued; their values are not used
-    }
+    // (Round 4 tried to stream a level's slice of the table into the L2s of its XCD group in front of the gathers -- every workgroup a
+    // share, coalesced 16-byte loads -- on the theory that small batches wait for sector-by-sector fills at the fabric's request rate.
+    // Same-box A/B, encode_kernel with / without: 256 rays 0.030 / 0.023 ms, 1 024: 0.066 / 0.060, 2 048: 0.114 / 0.108, 4 096: 0.199 /
+    // 0.199 -- the extra loads cost what they were meant to save and more; profiles/round4_ab_encoder_l2_warmup.jsonl.  Not kept.)
     dispatch_mode<Src::kInRange>(m.mode, [&](auto mode_tag) {
     constexpr uint32_t MODE = decltype(mode_tag)::value;
     const uint32_t stride = grid_x * blockDim.x;
@@ -201,8 +183,7 @@ static int launch_encode(const Src &src, const void *table, const int32_t *offse
     if ((flags & NAF_CFG_ENCODE_LEVEL_MAJOR) != 0u) log2g = 0u;
     while (log2g != 0u && nl % (1u << log2g) != 0u) --log2g;                 // a level range: as many groups as divide it
     const bool grouped = !interleaved && log2g != 0u && (nl >= 8u || nl != L);
-    // + 16: the level's slice is streamed into the L2s that gather from it (see the kernel); NAF_CFG_ENCODE_NO_WARM switches it off
-    const uint32_t order = interleaved ? 1u : grouped ? (4u + log2g) | ((flags & NAF_CFG_ENCODE_NO_WARM) != 0u ? 0u : 16u) : 0u;
+    const uint32_t order = interleaved ? 1u : grouped ? 4u + log2g : 0u;
     const dim3 grid = interleaved ? dim3(nl, gx) : grouped ? dim3((nl * gx + 7u) / 8u * 8u) : dim3(gx, nl);
     { ProfScope prof_("encode_kernel", s); hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src,
                        (const typename TT::store_t *)table, offsets, (typename FT::store_t *)feat, B, H, lv_begin, order, nl, L, gx, chunk, blc ? 1u : 0u); }

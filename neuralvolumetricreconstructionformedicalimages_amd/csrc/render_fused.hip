@@ -844,7 +844,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12 | NAF_CFG_ENCODE_NO_WARM)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1034,7 +1034,11 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
                                const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
-    constexpr uint32_t NT = 512u, PTS = 2u, kLvMany = 16u, kLvFew = 4u;
+#ifndef NAF_V2_LV_FEW
+#define NAF_V2_LV_FEW 4u      // levels per bin workgroup when tiles are scarce.  A/B builds (tools/build_variant.sh) override it: 2 gains 2 us at
+                              // 512 rays and loses 9 at 4 096, 8 the other way round (profiles/round4_ab_reducer_nt_loads_and_levels_per_bin_workgroup.jsonl)
+#endif
+    constexpr uint32_t NT = 512u, PTS = 2u, kLvMany = 16u, kLvFew = NAF_V2_LV_FEW;
     const BinPlan &plan = w.plan;
     const bool big = plan.tile_points == 2u * NT * PTS;
     if (!big && plan.tile_points != NT * PTS) return fail(NAF_ERR_LAUNCH, "binned scatter: plan / kernel tile mismatch");

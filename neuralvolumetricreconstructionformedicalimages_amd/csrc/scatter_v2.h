@@ -451,12 +451,20 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
 // 16 bytes per lane and array (two rows x two channels), operands requested in front of the record phase; kFast picks the form of
 // adam_math.h (tables with a 16-bit shadow).
 __device__ __forceinline__ int cvt_rpi(float v) {                // floor(v + 0.5): one instruction, no bias towards zero
-#ifdef NAF_V2_TRUNC
-    return (int)v;
-#else
-    int i;
+    int i;                                                        // (plain truncation measured the same: profiles/round4_ab_*)
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(v));
     return i;
+}
+
+// a record as one 8-byte load; NAF_V2_NT_LOADS (A/B builds, tools/build_variant.sh): non-temporal, so that records read once do not
+// displace the optimiser state -- measured flat at every batch size (profiles/round4_ab_reducer_nt_loads_and_levels_per_bin_workgroup.jsonl)
+__device__ __forceinline__ PairFx load_record(const PairFx *p) {
+#ifdef NAF_V2_NT_LOADS
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p));
+    return PairFx{v.x, v.y};
+#else
+    return *p;
 #endif
 }
 
@@ -550,7 +558,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
                     const uint32_t word = (uint32_t)__shfl((int)mine, (int)min(tl, 63u), 64);
                     n4[u] = tl < n_here ? word >> 16 : 0u;
                     b4[u] = blocks + block_index(plan, ly, t0 + min(tl, n_here - 1u)) + (word & 0xffffu);
-                    r4[u] = b4[u][j < n4[u] ? j : 0u];
+                    r4[u] = load_record(b4[u] + (j < n4[u] ? j : 0u));
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kSteps; ++u)
@@ -558,7 +566,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
 #pragma unroll 1
                 for (uint32_t u = 0; u < kSteps; ++u)
                     for (uint32_t i = W + j; __ballot(i < n4[u]) != 0ull; i += W)
-                        if (i < n4[u]) add(b4[u][i]);
+                        if (i < n4[u]) add(load_record(b4[u] + i));
             }
         }
     } else
@@ -576,7 +584,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
                 n[u] = j + u < n_here ? word >> 16 : 0u;
                 n_max = max(n_max, n[u]);
                 base[u] = blocks + block_index(plan, ly, t0 + tj) + (word & 0xffffu);
-                ra[u] = base[u][lane < n[u] ? lane : 0u];
+                ra[u] = load_record(base[u] + (lane < n[u] ? lane : 0u));
             }
             {
                 constexpr uint32_t kPer = 64u / kTail;                      // runs per tail instruction
@@ -592,7 +600,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
                         nt[q] = sub == k ? n[q * kPer + k] : nt[q];
                         bq = sub == k ? base[q * kPer + k] : bq;
                     }
-                    rt[q] = bq[slot < nt[q] ? slot : 0u];
+                    rt[q] = load_record(bq + (slot < nt[q] ? slot : 0u));
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kGroup; ++u)
@@ -604,7 +612,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
             if (n_max > 64u + kTail) {                                      // long runs (clustered tiles, merged levels' singles): the rest, run by run
 #pragma unroll 1
                 for (uint32_t u = 0; u < kGroup; ++u)
-                    for (uint32_t i = 64u + kTail + lane; i < n[u]; i += 64u) add(base[u][i]);
+                    for (uint32_t i = 64u + kTail + lane; i < n[u]; i += 64u) add(load_record(base[u] + i));
             }
         }
     }
