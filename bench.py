@@ -140,6 +140,17 @@ class ScanSampler:
             targets.append(t)
         return (targets[0] if len(targets) == 1 else torch.cat(targets)), rays_out
 
+    def plan(self, step, n, rays_out, target_out):
+        """The draw of `step` as a plan (struct naf_next_draw) for `NAFEngine.train_step(..., next_draw=...)`: the previous step takes
+        it along.  None when the draw needs more than one launch (more than 16 projections per step)."""
+        per = min(n, RAYS_PER_PROJECTION)
+        k = (n + per - 1) // per
+        if k * per != n or k > 16:
+            return None
+        lists = [self.valid[(step * k + j) % self.n_proj] for j in range(k)]
+        seed = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        return self.raygen.plan_draw(lists, per, seed, self.projs, rays_out, target_out)
+
     def draw_ranks(self, step, n, world, rays_out, target_out=None):
         """The draws of all `world` ranks of a step in ONE launch, in rank order (rank r: n distinct valid pixels of projection
         (step * world + r) mod n_proj): a level-parallel rank needs every rank's rays, and a shared seed makes them local."""
@@ -149,6 +160,26 @@ class ScanSampler:
         seed = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
         _, t, _ = self.raygen.draw(lists, n, seed, projections=self.projs, rays_out=rays_out, want_pixels=False, target_out=target_out)
         return t, rays_out
+
+
+class StepFeed:
+    """Double-buffered rays / targets of consecutive steps: step k's launches carry the pixel draw of step k + 1 (the data side of
+    tigre.py:354-372 stays inside the step -- one draw per step -- it just does not wait in line any more)."""
+
+    def __init__(self, sampler, n_rays, device):
+        self.sampler, self.n = sampler, n_rays
+        self.rays = [torch.empty(n_rays, 8, device=device) for _ in range(2)]
+        self.target = [torch.empty(n_rays, device=device) for _ in range(2)]
+        self.ready = None                                              # the step whose rays sit in buffer (step & 1)
+
+    def step(self, engine, i, weight, ray_base):
+        cur = i & 1
+        if self.ready != i:                                            # first step of a loop: draw it now
+            self.sampler.draw(i, self.n, self.rays[cur], self.target[cur])
+        nxt = self.sampler.plan(i + 1, self.n, self.rays[cur ^ 1], self.target[cur ^ 1])
+        loss = engine.train_step(self.rays[cur], self.target[cur], weight, ray_base=ray_base, next_draw=nxt)
+        self.ready = i + 1 if nxt is not None else None
+        return loss
 
 
 class ChestScan:
@@ -216,10 +247,11 @@ def psnr_race(scan, n_rays, lr, precision="bf16", thresholds=(30.0, 35.0, 38.0),
     rays = torch.empty(n_rays, 8, device=device)
     weight, loss_name = step_weights(n_rays, device)
 
+    feed = StepFeed(scan.sampler, n_rays, device)
+
     def run(engine, first, count):
         for i in range(first, first + count):
-            target, _ = scan.sampler.draw(i, n_rays, rays)
-            engine.train_step(rays, target, weight, ray_base=i * n_rays)
+            feed.step(engine, i, weight, i * n_rays)
 
     scratch = make_chest_engine(device, precision, lr, seed=seed)      # sizes the workspace, measures the step for the burst length
     run(scratch, 0, 3)
@@ -295,6 +327,7 @@ def full_schedule(scan, precision, seed=0, epochs=None, eval_epochs=25, threshol
     rays = torch.empty(n_rays, 8, device=device)
     weight, loss_name = step_weights(n_rays, device)
     engine = make_chest_engine(device, precision, lr0, seed=seed)
+    feed = StepFeed(scan.sampler, n_rays, device)
     curve = [{"train_s": 0.0, "epoch": 0, "steps": 0, "psnr_db": round(scan.volume_psnr(engine.net), 3)}]
     t_train, step = 0.0, 0
     for e0 in range(0, epochs, eval_epochs):
@@ -304,8 +337,7 @@ def full_schedule(scan, precision, seed=0, epochs=None, eval_epochs=25, threshol
         for e in range(e0, e1):
             engine.lr = lr0 * gamma ** (e // lr_step)              # StepLR: the scheduler steps at the END of every epoch (trainer.py:130)
             for _ in range(per_epoch):
-                target, _r = scan.sampler.draw(step, n_rays, rays)
-                engine.train_step(rays, target, weight, ray_base=step * n_rays)
+                feed.step(engine, step, weight, step * n_rays)
                 step += 1
         torch.cuda.synchronize()
         t_train += time.perf_counter() - t0
@@ -448,6 +480,8 @@ def main():
         rays_all = torch.empty(world * n, 8, device=device)
         target_all = torch.empty(world * n, device=device)
 
+    feed = StepFeed(sampler, n, device) if (world == 1 and not args.force_dp) else None
+
     def step(i, eng=None, n_rays=n, ray_buf=rays, w=weight):
         # G6 + G3 in one launch: distinct valid pixels, their measured values, their cone-beam rays (no host round trip).
         # (Drawing step k + 1 on a side stream while step k computes was measured and is not done: the event waits that order the two
@@ -456,6 +490,8 @@ def main():
             shared.draw_ranks(i, n_rays, world, rays_all, target_all)
             lo, hi = rank * n_rays, (rank + 1) * n_rays
             return engine.train_step(rays_all[lo:hi], target_all[lo:hi], w, ray_base=(i * world + rank) * n_rays, rays_all=rays_all)
+        if feed is not None and eng is None and n_rays == n:           # the main loop: step i carries the draw of step i + 1
+            return feed.step(engine, i, w, i * n_rays)
         target, _ = sampler.draw(i, n_rays, ray_buf)
         return (eng or engine).train_step(ray_buf, target, w, ray_base=(i * world + rank) * n_rays)
 

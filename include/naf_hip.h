@@ -351,6 +351,27 @@ int naf_render_train_adam(const float *rays, const float *t_rand, const float *t
                           float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
                           const naf_table_adam *adam, void *stream);
 
+/* The same step carrying the pixel draw of the NEXT step (G6, naf_draw_scan_rays): nothing in a step depends on the next step's
+ * pixels, and the draw is 6 us of latency in a launch of four workgroups, so the step takes it along in spare workgroups of the
+ * scatter's first launch (the canonical two-channel bf16 shape on the binned scatter; every other shape runs it as a launch of its
+ * own behind the step).  `next` holds the arguments of naf_draw_scan_rays; its rays / target buffers must not be the ones this step
+ * reads (double-buffer them).  NULL: exactly naf_render_train_adam. */
+typedef struct naf_next_draw {
+    naf_scan_draw draw;
+    const float *poses, *projections;
+    int64_t *pixels;           /* optional */
+    float *target;             /* optional */
+    float *rays;
+    uint32_t first_draw, n_draws, n_projections, det_w, det_h;
+    float du, dv, ou, ov, DSD, near, far;
+    int32_t parallel;
+    uint64_t seed;
+} naf_next_draw;
+int naf_render_train_adam_draw(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc, float *grad_embeddings,
+                               float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
+                               const naf_table_adam *adam, const naf_next_draw *next, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Level-parallel training for small steps on several GPUs (one process per GPU; no counterpart in the reference, which has no
  * distributed code -- it shards trainer.py:134-142 around train.py:48-135 like the data-parallel step does, with the same result).

@@ -81,6 +81,18 @@ class ScanDraw(ctypes.Structure):
     ]
 
 
+class NextDraw(ctypes.Structure):
+    """struct naf_next_draw (include/naf_hip.h): the arguments of naf_draw_scan_rays for the NEXT step's pixels."""
+    _fields_ = [
+        ("draw", ScanDraw), ("poses", ctypes.c_void_p), ("projections", ctypes.c_void_p), ("pixels", ctypes.c_void_p),
+        ("target", ctypes.c_void_p), ("rays", ctypes.c_void_p),
+        ("first_draw", ctypes.c_uint32), ("n_draws", ctypes.c_uint32), ("n_projections", ctypes.c_uint32), ("det_w", ctypes.c_uint32),
+        ("det_h", ctypes.c_uint32),
+        ("du", ctypes.c_float), ("dv", ctypes.c_float), ("ou", ctypes.c_float), ("ov", ctypes.c_float), ("DSD", ctypes.c_float),
+        ("near", ctypes.c_float), ("far", ctypes.c_float), ("parallel", ctypes.c_int32), ("seed", ctypes.c_uint64),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/naf_hip.h one to one (checked by tests/test_abi_symbols.py)
 _vp, _u32, _u64, _i32, _f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
@@ -112,6 +124,8 @@ SIGNATURES = {
                                          ctypes.POINTER(GradBuckets), _vp]),
     "naf_render_train_adam": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
                                      ctypes.POINTER(TableAdam), _vp]),
+    "naf_render_train_adam_draw": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
+                                          ctypes.POINTER(TableAdam), ctypes.POINTER(NextDraw), _vp]),
     "naf_levels_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp]),
     "naf_levels_field_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp, _vp]),
     "naf_levels_scatter": (_i32, [_vp, _vp, _vp, ctypes.c_size_t, _u32, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp,

@@ -1033,7 +1033,8 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 // The same launch plan with the kernels of scatter_v2.h (8-byte records; the canonical two-channel bf16 shape).
 static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
-                               const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
+                               const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
+                               DrawJob *next_draw = nullptr) {
 #ifndef NAF_V2_LV_FEW
 #define NAF_V2_LV_FEW 4u      // levels per bin workgroup when tiles are scarce.  A/B builds (tools/build_variant.sh) override it: 2 gains 2 us at
                               // 512 rays and loses 9 at 4 096, 8 the other way round (profiles/round4_ab_reducer_nt_loads_and_levels_per_bin_workgroup.jsonl)
@@ -1065,9 +1066,12 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
     if (slab_job != nullptr) job = *slab_job;
     auto launch_bin = [&](uint32_t l0, uint32_t nl) -> int {
         ProfScope prof_(per_level ? level_name(bin_names, l0) : "scatter_bin_kernel", s);
-        const uint32_t spare = job.slabs != nullptr ? kSlabReduceBlocks : 0u;
+        // the first launch of the step also carries the next step's pixel draw when the caller handed one over (spare workgroups)
+        DrawJob dj{};
+        if (next_draw != nullptr && next_draw->count != 0u) { dj = *next_draw; next_draw->count = 0u; }      // consumed
+        const uint32_t spare = (job.slabs != nullptr ? kSlabReduceBlocks : 0u) + (dj.count + threads - 1u) / threads;
         hipLaunchKernelGGL(bin, dim3(plan.n_tiles + spare, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const uint16_t *)dfeat,
-                           offsets, grad_table, (PairFx *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job);
+                           offsets, grad_table, (PairFx *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job, dj);
         job = SlabReduce{};
         return check_launch("scatter_bin_kernel");
     };
@@ -1100,10 +1104,11 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
 template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                     const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
-                                    const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
+                                    const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
+                                    DrawJob *next_draw = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
+        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job, next_draw);
         if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
         return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
     }
@@ -1128,9 +1133,9 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr) {
+                             const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr, DrawJob *next_draw = nullptr) {
     // (the overflow counters were zeroed by the MLP backward kernel of this call: StepExtras)
-    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam, slab_job);
+    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam, slab_job, next_draw);
     if (adam != nullptr) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: the Adam tail cannot be combined with gradient buckets");
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
         return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
@@ -1207,7 +1212,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
                                 void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
                                 const AdamTail *adam = nullptr, bool from_train = false, const LossInputs &loss = LossInputs{nullptr, nullptr, nullptr},
-                                float *loss_out = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
+                                float *loss_out = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
@@ -1231,20 +1236,20 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, defer ? &job : nullptr);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, defer ? &job : nullptr, next_draw);
 }
 
 template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
+                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
     if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true)) return rc;
     // the masked squared error and its gradient are formed inside the backward kernel (LossInputs); the loss reaches loss_out
     // through the slab reduction that also finishes the MLP gradient
     const LossInputs loss{acc, target, ray_weight};
     return render_backward_impl<P, C>(rays, t_rand, nullptr, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true,
-                                      loss, loss_out, madam, loss_assign);
+                                      loss, loss_out, madam, loss_assign, next_draw);
 }
 
 template <typename P, uint32_t C>
@@ -1501,7 +1506,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream,
-                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false) {
+                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
@@ -1520,7 +1525,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
         return NAF_OK;
     }
     NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam, loss_assign);
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam, loss_assign, next_draw);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
@@ -1542,10 +1547,10 @@ extern "C" int naf_render_train_bucketed(const float *rays, const float *t_rand,
 
 static_assert(kAdamLpF16 == NAF_F16 && kAdamLpBF16 == NAF_BF16, "adam_math.h mirrors naf_dtype");
 
-extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
-                                     const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
-                                     float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                                     const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream) {
+static int render_train_adam_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                  const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                  float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                  const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream, DrawJob *next_draw) {
     if (!adam) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null adam");
     if (!adam->param || !adam->exp_avg || !adam->exp_avg_sq || !grad_embeddings) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null pointer");
     if (adam->step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: step is 1-based");
@@ -1570,12 +1575,41 @@ extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, con
     const uint64_t n_points = (uint64_t)n_rays * cfg->n_samples;
     if (n_rays != 0 && workspace != nullptr && n_points < (1ull << 31) && adam_tail_possible(cfg, carve(workspace, cfg, n_points)))
         return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp, true);
+                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp, true, next_draw);
     // small batches (atomic scatter), split reducer launches, per-level diagnostics, empty batches: the two passes one after the other
     if (int rc = render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
                                     n_rays, cfg, workspace, nullptr, stream, nullptr, mp, true)) return rc;
     return launch_adam(adam->param, adam->exp_avg, adam->exp_avg_sq, grad_embeddings, adam->param_lp, adam->lp_dtype, adam->n, tail.a,
                        true, (hipStream_t)stream);
+}
+
+extern "C" int naf_render_train_adam(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                     const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                     float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                     const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream) {
+    return render_train_adam_impl(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out, n_rays,
+                                  cfg, workspace, adam, stream, nullptr);
+}
+
+// ... and the same step carrying the pixel draw of the NEXT one (naf_hip.h): in spare workgroups of pass 1 of the binned scatter where
+// the step runs it (the canonical bf16 shape), as a launch of its own behind the step everywhere else -- same results either way.
+extern "C" int naf_render_train_adam_draw(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
+                                          const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
+                                          float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
+                                          const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam,
+                                          const naf_next_draw *next, void *stream) {
+    if (next == nullptr)
+        return render_train_adam_impl(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out, n_rays,
+                                      cfg, workspace, adam, stream, nullptr);
+    if (next->rays == rays || (next->target != nullptr && next->target == target))
+        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_draw: the next step's rays / targets must not be the buffers this step reads");
+    DrawJob job;
+    if (int rc = make_draw_job(&next->draw, next->poses, next->projections, next->pixels, next->target, next->rays, next->first_draw, next->n_draws,
+                               next->n_projections, next->det_w, next->det_h, next->du, next->dv, next->ou, next->ov, next->DSD, next->near,
+                               next->far, next->parallel, next->seed, &job)) return rc;
+    if (int rc = render_train_adam_impl(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out, n_rays,
+                                        cfg, workspace, adam, stream, &job)) return rc;
+    return launch_draw(job, (hipStream_t)stream);            // count == 0 when pass 1 took it along
 }
 
 /* ---- level-parallel training (naf_hip.h) --------------------------------------------------------------------------------- */

@@ -6,6 +6,7 @@
 
 #include "naf_device.h"
 #include "naf_host.h"
+#include "draw_device.h"
 
 namespace naf {
 
@@ -308,43 +309,6 @@ extern "C" int naf_normalize_inputs(const float *x, uint64_t n, float size, floa
 // 720x1024^2); here a ray is 32 bytes produced on demand from its pose and pixel.
 namespace naf {
 
-struct RayGeo {
-    uint32_t W, H;          // detector columns / rows (nDetector[0], nDetector[1])
-    float du, dv;           // pixel pitch  (dDetector)
-    float ou, ov;           // detector offset (offDetector)
-    float DSD;
-    float near, far;        // tigre.py:575-586
-    int parallel;           // 0 cone, 1 parallel
-};
-
-__device__ __forceinline__ void make_ray(const float *__restrict__ poses, uint64_t flat, const RayGeo &g, float4 *out) {
-    const uint64_t per_proj = (uint64_t)g.W * g.H;
-    const uint32_t proj = (uint32_t)(flat / per_proj);
-    const uint32_t rem = (uint32_t)(flat - (uint64_t)proj * per_proj);
-    const uint32_t row = rem / g.W, col = rem - row * g.W;
-    const float *P = poses + (size_t)proj * 12;                 // 3x4 row-major [R | t]
-    // tigre.py:423-429: uu along columns, vv along rows
-    const float uu = ((float)col + 0.5f - (float)g.W / 2.0f) * g.du + g.ou;
-    const float vv = ((float)row + 0.5f - (float)g.H / 2.0f) * g.dv + g.ov;
-    float o[3], d[3];
-    if (!g.parallel) {                                          // tigre.py:434-437
-        const float dx = uu / g.DSD, dy = vv / g.DSD;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            d[k] = P[4 * k + 0] * dx + P[4 * k + 1] * dy + P[4 * k + 2];
-            o[k] = P[4 * k + 3];
-        }
-    } else {                                                    // tigre.py:438-447
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            d[k] = P[4 * k + 2];
-            o[k] = P[4 * k + 0] * uu + P[4 * k + 1] * vv + P[4 * k + 3];
-        }
-    }
-    out[0] = make_float4(o[0], o[1], o[2], d[0]);
-    out[1] = make_float4(d[1], d[2], g.near, g.far);
-}
-
 __global__ void __launch_bounds__(256)
 generate_rays_kernel(const float *__restrict__ poses, const int64_t *__restrict__ pixels, int64_t first_pixel,
                      float *__restrict__ rays, uint64_t n, RayGeo g, uint64_t n_pixels) {
@@ -360,67 +324,16 @@ generate_rays_kernel(const float *__restrict__ poses, const int64_t *__restrict_
     }
 }
 
-// ---- G6: the data side of a training step on the device (reference src/dataset/tigre.py:354-372) ------------------
-// `np.random.choice(valid, n_rays, replace=False)` + three fancy-indexing gathers per item become ONE launch: draw index i
-// is sent through a keyed bijection of [0, n_valid) (a 4-round Feistel network on the smallest even-width bit field that
-// covers n_valid, restricted to the range by cycle walking), so the first n outputs are n DISTINCT uniformly chosen
-// entries of the valid-pixel list -- no sort, no host synchronisation, and ranks of a data-parallel job that share the
-// seed can each take a slice of the same draw.  The thread then gathers the measured value and generates the ray.
-struct ScanDraw {
-    uint32_t n_segments, per_segment;
-    const int64_t *valid[NAF_MAX_DRAW_SEGMENTS];
-    uint32_t n_valid[NAF_MAX_DRAW_SEGMENTS];
-};
-
-__device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_t n, uint32_t half_bits, uint64_t seed) {
-    const uint32_t mask = (1u << half_bits) - 1u;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t x = i;
-    do {                                                     // the walk stays inside the cycle of i: still a bijection on [0, n)
-        uint32_t l = x >> half_bits, r = x & mask;
-#pragma unroll
-        for (uint32_t round = 0; round < 4u; ++round) {
-            const uint32_t f = mix32(r ^ (round & 1u ? k1 : k0) ^ (0x9e3779b9u * (round + 1u))) & mask;
-            const uint32_t t = l ^ f;
-            l = r;
-            r = t;
-        }
-        x = (l << half_bits) | r;
-    } while (x >= n);
-    return x;
-}
-
 __global__ void __launch_bounds__(256)
-draw_scan_rays_kernel(ScanDraw draw, const float *__restrict__ poses, const float *__restrict__ projections,
-                      int64_t *__restrict__ pixels, float *__restrict__ target, float *__restrict__ rays, uint32_t first,
-                      uint32_t count, RayGeo g, uint64_t seed, uint64_t n_pixels) {
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
-        const uint32_t i = first + t;                           // global draw index: segment-major
-        const uint32_t seg = i / draw.per_segment, k = i - seg * draw.per_segment;
-        const uint32_t n = draw.n_valid[seg];
-        uint32_t half_bits = 1u;
-        while ((1ull << (2u * half_bits)) < (uint64_t)n) ++half_bits;
-        const uint32_t idx = feistel_permute(k, n, half_bits, seed + 0x632be59bd9b4e019ull * (seg + 1u));
-        const int64_t flat = draw.valid[seg][idx];
-        if (pixels) pixels[t] = flat;
-        if ((uint64_t)flat >= n_pixels) {                       // a list entry outside the scan (the reference's fancy index would raise):
-            const float nan = __builtin_nanf("");               // nothing is read through it, the ray and its value are NaN
-            if (target) target[t] = nan;
-            reinterpret_cast<float4 *>(rays + (size_t)t * 8)[0] = make_float4(nan, nan, nan, nan);
-            reinterpret_cast<float4 *>(rays + (size_t)t * 8)[1] = make_float4(nan, nan, g.near, g.far);
-            continue;
-        }
-        if (target) target[t] = projections[flat];
-        make_ray(poses, (uint64_t)flat, g, reinterpret_cast<float4 *>(rays + (size_t)t * 8));
-    }
+draw_scan_rays_kernel(DrawJob job) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < job.count; t += gridDim.x * blockDim.x) draw_one(job, t);
 }
 
 }  // namespace naf
 
-extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses, const float *projections, int64_t *pixels,
-                                  float *target, float *rays, uint32_t first_draw, uint32_t n_draws, uint32_t n_projections,
-                                  uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov, float DSD, float near,
-                                  float far, int parallel, uint64_t seed, void *stream) {
+int naf::make_draw_job(const naf_scan_draw *draw, const float *poses, const float *projections, int64_t *pixels, float *target, float *rays,
+                       uint32_t first_draw, uint32_t n_draws, uint32_t n_projections, uint32_t det_w, uint32_t det_h, float du, float dv,
+                       float ou, float ov, float DSD, float near, float far, int parallel, uint64_t seed, DrawJob *job) {
     if (!draw || (n_draws != 0 && (!poses || !rays))) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: null pointer");
     if (n_draws != 0 && target && !projections) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: target without projections");
     if (draw->n_segments == 0 || draw->n_segments > NAF_MAX_DRAW_SEGMENTS || draw->rays_per_segment == 0)
@@ -430,7 +343,7 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
     const uint64_t total = (uint64_t)draw->n_segments * draw->rays_per_segment;
     if (total > 0xffffffffull) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: more than 2^32 - 1 draws per call");
     if ((uint64_t)first_draw + n_draws > total) return fail(NAF_ERR_INVALID_ARGUMENT, "draw_scan_rays: draw range outside n_segments * rays_per_segment");
-    ScanDraw d;
+    ScanDraw &d = job->draw;
     d.n_segments = draw->n_segments;
     d.per_segment = draw->rays_per_segment;
     for (uint32_t j = 0; j < NAF_MAX_DRAW_SEGMENTS; ++j) {
@@ -442,12 +355,28 @@ extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses,
         if (used && draw->n_valid[j] < draw->rays_per_segment)
             return fail(NAF_ERR_INVALID_ARGUMENT, "Cannot take a larger sample than population when 'replace=False'");
     }
-    if (n_draws == 0) return NAF_OK;
-    RayGeo g{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
-    { ProfScope prof_("draw_scan_rays_kernel", (hipStream_t)stream);
-      hipLaunchKernelGGL(draw_scan_rays_kernel, dim3(grid_for(n_draws, 256)), dim3(256), 0, (hipStream_t)stream, d, poses, projections,
-                         pixels, target, rays, first_draw, n_draws, g, seed, (uint64_t)n_projections * det_w * det_h); }
+    job->poses = poses; job->projections = projections; job->pixels = pixels; job->target = target; job->rays = rays;
+    job->first = first_draw; job->count = n_draws;
+    job->g = RayGeo{det_w, det_h, du, dv, ou, ov, DSD, near, far, parallel};
+    job->seed = seed; job->n_pixels = (uint64_t)n_projections * det_w * det_h;
+    return NAF_OK;
+}
+
+int naf::launch_draw(const DrawJob &job, hipStream_t stream) {
+    if (job.count == 0) return NAF_OK;
+    { ProfScope prof_("draw_scan_rays_kernel", stream);
+      hipLaunchKernelGGL(draw_scan_rays_kernel, dim3(grid_for(job.count, 256)), dim3(256), 0, stream, job); }
     return check_launch("draw_scan_rays_kernel");
+}
+
+extern "C" int naf_draw_scan_rays(const naf_scan_draw *draw, const float *poses, const float *projections, int64_t *pixels,
+                                  float *target, float *rays, uint32_t first_draw, uint32_t n_draws, uint32_t n_projections,
+                                  uint32_t det_w, uint32_t det_h, float du, float dv, float ou, float ov, float DSD, float near,
+                                  float far, int parallel, uint64_t seed, void *stream) {
+    DrawJob job;
+    if (int rc = make_draw_job(draw, poses, projections, pixels, target, rays, first_draw, n_draws, n_projections, det_w, det_h, du, dv, ou, ov,
+                               DSD, near, far, parallel, seed, &job)) return rc;
+    return launch_draw(job, (hipStream_t)stream);
 }
 
 extern "C" int naf_generate_rays(const float *poses, const int64_t *pixels, int64_t first_pixel, float *rays, uint64_t n,

@@ -29,6 +29,7 @@
 // replaces the fp64 route (26 significant bits below the step's largest gradient: two more than the fp32 mantissa the atomic path sums with).
 #pragma once
 
+#include "draw_device.h"
 #include "hash_kernels.h"
 #include "scatter_binned.h"
 
@@ -105,11 +106,19 @@ template <uint32_t NT, uint32_t LV, uint32_t kLog2NB>            // kLog2NB: 6 =
 __global__ void __launch_bounds__(NT, 4)                       // 512 threads: two workgroups per CU; 1024: one -- 16 waves either way
 scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
                     PairFx *__restrict__ blocks, uint32_t *__restrict__ runs, uint32_t *__restrict__ overflow, uint32_t B, uint32_t H,
-                    uint32_t level_base, uint32_t n_levels, BinPlan plan, SlabReduce slab_job) {
+                    uint32_t level_base, uint32_t n_levels, BinPlan plan, SlabReduce slab_job, DrawJob draw_job) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x >= plan.n_tiles) {                              // spare workgroups: the MLP backward's slab reduction (scatter_binned.h)
-        if (blockIdx.y == 0u && slab_job.slabs != nullptr)
-            slab_reduce_block<NT / kReduceParams>(reinterpret_cast<float (*)[kReduceParams]>(smem), slab_job, blockIdx.x - plan.n_tiles, threadIdx.x);
+    if (blockIdx.x >= plan.n_tiles) {
+        // spare workgroups behind the tiles: the MLP backward's slab reduction (scatter_binned.h), then -- naf_render_train_adam_draw --
+        // the pixel draw of the NEXT step (draw_device.h): nothing in this step depends on either
+        if (blockIdx.y == 0u) {
+            const uint32_t spare = blockIdx.x - plan.n_tiles, n_slab = slab_job.slabs != nullptr ? kSlabReduceBlocks : 0u;
+            if (spare < n_slab) slab_reduce_block<NT / kReduceParams>(reinterpret_cast<float (*)[kReduceParams]>(smem), slab_job, spare, threadIdx.x);
+            else {
+                const uint32_t t = (spare - n_slab) * NT + threadIdx.x;
+                if (t < draw_job.count) draw_one(draw_job, t);
+            }
+        }
         return;
     }
     constexpr uint32_t PTS = 2u;

@@ -640,11 +640,14 @@ class NAFEngine:
                                               float(self.net.bound), cfg.seed, int(ray_base), _abi.stream_ptr()), "sample_rays")
         return z
 
-    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None, global_ray_base=None):
+    def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None, global_ray_base=None,
+                   next_draw=None):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync).  `raw_noise_std` > 0 (render.py:196-199): the per-sample noise on sigma adds sum_s noise_s * dist_s to a
         ray's line integral and nothing else (render.noise_line_integral), so the step runs on target - that term; `noise`: explicit
-        N(0, 1) draws [n, S] instead of torch.randn.  `rays_all` / `global_ray_base`: level-parallel steps only (_train_step_levels)."""
+        N(0, 1) draws [n, S] instead of torch.randn.  `rays_all` / `global_ray_base`: level-parallel steps only (_train_step_levels).
+        `next_draw` (`RayGenerator.plan_draw`): the pixel draw of the NEXT step, carried along by this one (naf_render_train_adam_draw:
+        spare workgroups of the scatter's first launch on the fused single-GPU path, a launch of its own behind the step otherwise)."""
         n = rays.shape[0]
         if float(raw_noise_std) > 0.0 and n > 0:
             from .render import noise_line_integral
@@ -652,7 +655,8 @@ class NAFEngine:
         if self.dp_mode == "levels" and self.process_group is not None:
             self._train_step_levels(rays, target, weight, t_rand, ray_base, rays_all, global_ray_base)
         elif self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
-            self._train_step_fused_adam(rays, target, weight, t_rand, ray_base)
+            self._train_step_fused_adam(rays, target, weight, t_rand, ray_base, next_draw)
+            next_draw = None
         else:
             self.backward(rays, target, weight, t_rand, ray_base)
             if self._dp is not None and self.dp_mode == "sharded":
@@ -661,10 +665,12 @@ class NAFEngine:
                 self._exchange_and_step()
             else:
                 self.optimizer_step()
+        if next_draw is not None:
+            next_draw.launch()                                 # every other route: the draw as a launch of its own behind the step
         self.rays_seen += n
         return self.loss
 
-    def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base):
+    def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base, next_draw=None):
         """backward() + optimizer_step() in ONE library call: naf_render_train_adam -- the gradient reducer finishes every table
         row with its Adam update, the slab reduction of the MLP gradient does the same for the 4 225 MLP parameters."""
         n = rays.shape[0]
@@ -680,10 +686,13 @@ class NAFEngine:
         st.lp_dtype = 0 if self.emb_lp is None else _abi.dtype_code(self.table_dtype)
         st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = self.emb.numel(), self.lr, b1, b2, self.eps, self.step_count, 1.0
         st.mlp_param, st.mlp_exp_avg, st.mlp_exp_avg_sq = self.mlp.data_ptr(), self.mlp_m.data_ptr(), self.mlp_v.data_ptr()
-        _abi.check(_abi.lib().naf_render_train_adam(
-            _abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
-            _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
-            ctypes.byref(cfg), _abi.ptr(ws), ctypes.byref(st), _abi.stream_ptr()), "render_train_adam")
+        args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
+                _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
+                ctypes.byref(cfg), _abi.ptr(ws), ctypes.byref(st))
+        if next_draw is None:
+            _abi.check(_abi.lib().naf_render_train_adam(*args, _abi.stream_ptr()), "render_train_adam")
+        else:
+            _abi.check(_abi.lib().naf_render_train_adam_draw(*args, ctypes.byref(next_draw), _abi.stream_ptr()), "render_train_adam_draw")
         fused._bump(self.device)                               # (the MLP's update rode on the slab reduction of that call)
 
     # ---- optimiser state in torch.optim.Adam's layout (checkpoint compatibility, trainer.py:118-126) ---------

@@ -131,6 +131,38 @@ class RayGenerator:
             int(g.mode == "parallel"), int(seed) & (2 ** 64 - 1), _abi.stream_ptr()), "draw_scan_rays")
         return pixels, target, rays
 
+    def plan_draw(self, valid_lists, rays_per_list, seed, projections, rays_out, target_out, first=0, count=None):
+        """The arguments of `draw` as a `_abi.NextDraw` (struct naf_next_draw) instead of a launch: `NAFEngine.train_step(...,
+        next_draw=plan)` lets step k carry the pixel draw of step k + 1 in spare workgroups of its own launches.  `rays_out` [count, 8]
+        and `target_out` [count] must not be the buffers step k reads (double-buffer them).  `plan.launch()` runs it stand-alone."""
+        g = self.geo
+        k = len(valid_lists)
+        count = k * int(rays_per_list) - first if count is None else int(count)
+        nd = _abi.NextDraw()
+        nd.draw.n_segments, nd.draw.rays_per_segment = k, int(rays_per_list)
+        for j, v in enumerate(valid_lists):
+            if v.dtype != torch.int64 or not v.is_cuda or not v.is_contiguous():
+                raise RuntimeError("draw: valid-pixel lists must be contiguous int64 device tensors")
+            if v.numel() < rays_per_list:
+                raise ValueError("Cannot take a larger sample than population when 'replace=False'")      # tigre.py:357
+            nd.draw.valid[j], nd.draw.n_valid[j] = v.data_ptr(), v.numel()
+        nd.poses, nd.projections = self.poses.data_ptr(), projections.data_ptr()
+        nd.pixels, nd.target, nd.rays = None, target_out.data_ptr(), rays_out.data_ptr()
+        nd.first_draw, nd.n_draws, nd.n_projections, nd.det_w, nd.det_h = int(first), count, self.n_projections, self.W, self.H
+        nd.du, nd.dv, nd.ou, nd.ov = float(g.dDetector[0]), float(g.dDetector[1]), float(g.offDetector[0]), float(g.offDetector[1])
+        nd.DSD, nd.near, nd.far, nd.parallel = float(g.DSD), float(self.near), float(self.far), int(g.mode == "parallel")
+        nd.seed = int(seed) & (2 ** 64 - 1)
+        nd._keep = (valid_lists, projections, rays_out, target_out)        # the struct holds raw pointers
+
+        def launch():
+            import ctypes
+            _abi.check(_abi.lib().naf_draw_scan_rays(
+                ctypes.byref(nd.draw), nd.poses, nd.projections, None, nd.target, nd.rays, nd.first_draw, nd.n_draws, nd.n_projections,
+                nd.det_w, nd.det_h, nd.du, nd.dv, nd.ou, nd.ov, nd.DSD, nd.near, nd.far, nd.parallel, nd.seed, _abi.stream_ptr()),
+                "draw_scan_rays")
+        nd.launch = launch
+        return nd
+
     def rays_for_pixels(self, pixels, out=None):
         """pixels: int64 [n] flat indices proj*H*W + row*W + col  ->  rays [n,8]."""
         pixels = pixels.contiguous().to(torch.int64)

@@ -49,6 +49,25 @@ rm -rf $OUT/stats_1024 $OUT/stats_65536 $OUT/fetch_1024 $OUT/fetch_65536 $OUT/wr
 ls gpurun_out/profiles_staged
 exit 0
 fi
+if [ "$PART" = C ]; then
+# ---- part C (round 4): the short half of part B -- evaluation, train.py's loop, the other BASELINE shapes, level-parallel emulation
+rm -f $OUT/eval.jsonl $OUT/shapes.jsonl $OUT/levels_emulation.jsonl
+for f in "" "--precision fp32"; do
+  timeout -k 10 200 python tools/eval_bench.py $f >> $OUT/eval.jsonl 2>> $OUT/eval.err
+done
+timeout -k 10 300 python tools/train_throughput.py 2> $OUT/train_py.err | grep "^{" | tail -n 1 > $OUT/train_py.json
+for a in "--log2T 22 --samples 320 --table fp16 --rays 32768" "--log2T 21 --samples 192 --table bf16 --rays 32768" "--log2T 20 --samples 192 --table bf16 --rays 65536" "--log2T 19 --samples 576 --table bf16 --rays 16384" "--log2T 19 --samples 192 --table bf16 --rays 65536" "--log2T 19 --samples 320 --table bf16 --rays 1024" "--log2T 19 --samples 576 --table bf16 --rays 1024 --steps 100"; do
+  timeout -k 10 100 python tools/step_bench.py $a 2>> $OUT/shapes.err | tail -n 1 >> $OUT/shapes.jsonl
+done
+for n in 2 4 8; do
+  timeout -k 10 200 python tools/levels_emulate.py --ranks $n 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+done
+timeout -k 10 300 python tools/levels_emulate.py --ranks 8 --rays 1024 --log2T 22 --samples 320 --table fp16 2>> $OUT/levels.err | tail -n 1 >> $OUT/levels_emulation.jsonl
+timeout -k 10 200 python bench.py --force-dp --dp-mode levels --steps 1000 --psnr-seconds 0 --cpu-seconds 0 --sub-records 0 --full-schedule 0 2> $OUT/levels_one_rank.err | tail -n 1 > $OUT/bench_level_parallel_one_rank.json
+NAF_PROFILES_DST=gpurun_out/profiles_staged python tools/install_profiles.py ${NAF_TAG:-round4}
+ls gpurun_out/profiles_staged
+exit 0
+fi
 # ---- part B: evaluation side, train.py loop, other BASELINE shapes, T = 2^22 fetch bytes, PSNR curves and the time-to-PSNR grid ----
 rm -f $OUT/eval.jsonl $OUT/shapes.jsonl $OUT/psnr_race_grid.jsonl
 for f in "" "--precision fp32" "--fused" "--fused --store-features"; do

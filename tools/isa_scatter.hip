@@ -13,8 +13,8 @@ template __global__ void scatter_reduce_kernel<2, PairBF16<2>, false>(const Pair
 }
 #include "scatter_v2.h"
 namespace naf {
-template __global__ void scatter_bin2_kernel<512, 16, 6>(SrcRays, const uint16_t *, const int32_t *, float *, PairFx *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce);
-template __global__ void scatter_bin2_kernel<1024, 16, 0>(SrcRays, const uint16_t *, const int32_t *, float *, PairFx *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce);
+template __global__ void scatter_bin2_kernel<512, 16, 6>(SrcRays, const uint16_t *, const int32_t *, float *, PairFx *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce, DrawJob);
+template __global__ void scatter_bin2_kernel<1024, 16, 0>(SrcRays, const uint16_t *, const int32_t *, float *, PairFx *, uint32_t *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, BinPlan, SlabReduce, DrawJob);
 }
 namespace naf {
 template __global__ void scatter_reduce2_kernel<true, true>(const PairFx *, const uint32_t *, const int32_t *, float *, const uint32_t *, uint32_t, uint32_t, uint32_t, BinPlan, AdamTail);
