@@ -95,10 +95,20 @@ __device__ __forceinline__ bf16x8 pack16(const f32x4v &lo, const f32x4v &hi) {
     for (int j = 0; j < 4; ++j) { v[j] = (__bf16)lo[j]; v[4 + j] = (__bf16)hi[j]; }
     return v;
 }
+// max(z, 0.01 z) == LeakyReLU(z).  fmaxf() on an MFMA result costs a third instruction per value (the compiler quiets a possible
+// signalling NaN with v_max z, z first): 24 of the 119 vector instructions of a forward tile.  The v_max is therefore spelled out.
+// Its second operand is the product the compiler schedules itself -- behind the wait states the MFMA result needs -- so the
+// hand-written instruction can never read the accumulator early (the hazard recogniser does not look into inline asm; see
+// leaky_inplace in field_mlp.h, where the operand did not depend on such a product).
+__device__ __forceinline__ float max_plain(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f32x4v leaky4(const f32x4v &z) {
     f32x4v h;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = fmaxf(z[j], kLeaky * z[j]);
+    for (int j = 0; j < 4; ++j) h[j] = max_plain(z[j], kLeaky * z[j]);
     return h;
 }
 
@@ -109,28 +119,59 @@ struct Act16 {
     bf16x8 h1f, h2f;
 };
 
+// Where a tile's forward takes its weights from.  FromLds re-reads every fragment and bias vector per tile (the backward kernel:
+// hoisted they would pin ~90 registers there); InRegs holds the lane's share of all four layers -- 12 fragments, 3 bias vectors, w3,
+// b3: 81 registers -- for the forward kernel, whose tile loop then touches the LDS for nothing but the depths.  (The compiler used to
+// hoist FromLds' reads out of that loop by itself; it stops doing so as soon as the loop body contains an asm statement, which it
+// cannot prove to return, so the choice is made explicit.)
+struct Mlp16FromLds {
+    const unsigned char *shared;
+    uint32_t lane;
+    __device__ __forceinline__ bf16x8 frag(uint32_t f, uint32_t o) const { return Mlp16Shared::frag(shared, f, o, lane); }
+    __device__ __forceinline__ void vec8(uint32_t k, f32x4v &lo, f32x4v &hi) const { Mlp16Shared::vec8(shared, k, lane >> 4, lo, hi); }
+    __device__ __forceinline__ float b3() const { return Mlp16Shared::b3(shared); }
+};
+struct Mlp16InRegs {
+    bf16x8 w[4][2];                    // kFW0, kFW1, kFW2a, kFW2b x output half
+    f32x4v vlo[4], vhi[4];             // b0 b1 b2 w3 at the lane's features
+    float bias3;
+    __device__ __forceinline__ void load(const unsigned char *shared, uint32_t lane) {
+        static_assert(kFW0 == 0 && kFW1 == 1 && kFW2a == 2 && kFW2b == 3, "forward fragments come first");
+#pragma unroll
+        for (uint32_t f = 0; f < 4; ++f)
+#pragma unroll
+            for (uint32_t o = 0; o < 2; ++o) w[f][o] = Mlp16Shared::frag(shared, f, o, lane);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) Mlp16Shared::vec8(shared, k, lane >> 4, vlo[k], vhi[k]);
+        bias3 = Mlp16Shared::b3(shared);
+    }
+    __device__ __forceinline__ bf16x8 frag(uint32_t f, uint32_t o) const { return w[f][o]; }
+    __device__ __forceinline__ void vec8(uint32_t k, f32x4v &lo, f32x4v &hi) const { lo = vlo[k]; hi = vhi[k]; }
+    __device__ __forceinline__ float b3() const { return bias3; }
+};
+
 // Forward of one 16-point tile.  x0f: the lane's layer-0 operand (its eight bf16 features).  Returns z4, the pre-activation
 // of the output unit for point c = lane & 15 (all four lane groups hold the same value).
-__device__ __forceinline__ float mlp16_tile_forward(const unsigned char *shared, uint32_t lane, const bf16x8 &x0f, Act16 &a) {
-    const uint32_t g = lane >> 4;
+template <typename W>
+__device__ __forceinline__ float mlp16_tile_forward(const W &wt, const bf16x8 &x0f, Act16 &a) {
     f32x4v blo, bhi;
-    Mlp16Shared::vec8(shared, 0, g, blo, bhi);
-    f32x4v zlo = mma16(Mlp16Shared::frag(shared, kFW0, 0, lane), x0f, blo);
-    f32x4v zhi = mma16(Mlp16Shared::frag(shared, kFW0, 1, lane), x0f, bhi);
+    wt.vec8(0, blo, bhi);
+    f32x4v zlo = mma16(wt.frag(kFW0, 0), x0f, blo);
+    f32x4v zhi = mma16(wt.frag(kFW0, 1), x0f, bhi);
     a.h1lo = leaky4(zlo); a.h1hi = leaky4(zhi);
     a.h1f = pack16(a.h1lo, a.h1hi);
-    Mlp16Shared::vec8(shared, 1, g, blo, bhi);
-    zlo = mma16(Mlp16Shared::frag(shared, kFW1, 0, lane), a.h1f, blo);
-    zhi = mma16(Mlp16Shared::frag(shared, kFW1, 1, lane), a.h1f, bhi);
+    wt.vec8(1, blo, bhi);
+    zlo = mma16(wt.frag(kFW1, 0), a.h1f, blo);
+    zhi = mma16(wt.frag(kFW1, 1), a.h1f, bhi);
     a.h2lo = leaky4(zlo); a.h2hi = leaky4(zhi);
     a.h2f = pack16(a.h2lo, a.h2hi);
-    Mlp16Shared::vec8(shared, 2, g, blo, bhi);
-    zlo = mma16(Mlp16Shared::frag(shared, kFW2a, 0, lane), x0f, blo);          // skip connection: cat([input, h2])
-    zhi = mma16(Mlp16Shared::frag(shared, kFW2a, 1, lane), x0f, bhi);
-    zlo = mma16(Mlp16Shared::frag(shared, kFW2b, 0, lane), a.h2f, zlo);
-    zhi = mma16(Mlp16Shared::frag(shared, kFW2b, 1, lane), a.h2f, zhi);
+    wt.vec8(2, blo, bhi);
+    zlo = mma16(wt.frag(kFW2a, 0), x0f, blo);                                  // skip connection: cat([input, h2])
+    zhi = mma16(wt.frag(kFW2a, 1), x0f, bhi);
+    zlo = mma16(wt.frag(kFW2b, 0), a.h2f, zlo);
+    zhi = mma16(wt.frag(kFW2b, 1), a.h2f, zhi);
     a.h3lo = leaky4(zlo); a.h3hi = leaky4(zhi);
-    Mlp16Shared::vec8(shared, 3, g, a.w3lo, a.w3hi);                            // w3 at the lane's features
+    wt.vec8(3, a.w3lo, a.w3hi);                                                // w3 at the lane's features
     float part = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) part = __fmaf_rn(a.w3lo[j], a.h3lo[j], part);
@@ -138,17 +179,39 @@ __device__ __forceinline__ float mlp16_tile_forward(const unsigned char *shared,
     for (int j = 0; j < 4; ++j) part = __fmaf_rn(a.w3hi[j], a.h3hi[j], part);
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
-    return part + Mlp16Shared::b3(shared);
+    return part + wt.b3();
+}
+__device__ __forceinline__ float mlp16_tile_forward(const unsigned char *shared, uint32_t lane, const bf16x8 &x0f, Act16 &a) {
+    return mlp16_tile_forward(Mlp16FromLds{shared, lane}, x0f, a);
 }
 
 // The lane's layer-0 operand for C = 2: four dwords of the [L, B, 2] bf16 feature tensor (levels 2g, 2g+1, 8+2g, 9+2g).
 struct Feat16Raw { uint32_t w[4]; };
+// The four addresses are ONE per-lane address (level 2g, point p) plus the wave-uniform distances B, 8B, 9B.  Written as four
+// independent index expressions the compiler keeps four loop-invariant 64-bit bases per lane alive across the tile loop (and as
+// many again for the gradient stores): 16 registers, which the backward kernel paid for with spills whose reloads wait for
+// vmcnt(0) -- i.e. for the prefetch of the next tile -- in the middle of every tile.  The empty asm hides the sum from the
+// reassociation that would rebuild those bases.
+__device__ __forceinline__ size_t feat16_lane_index(uint32_t B, uint32_t p, uint32_t g) {
+    size_t i = (size_t)(2u * g) * B + p;                                      // level 2g, point p; one dword = (channel 0, channel 1)
+    asm("" : "+v"(i));
+    return i;
+}
 __device__ __forceinline__ void load_feat16(const uint16_t *__restrict__ feat, uint32_t B, uint32_t p, uint32_t g, Feat16Raw &raw) {
-    const uint32_t *f32 = reinterpret_cast<const uint32_t *>(feat);            // one dword = (channel 0, channel 1) of a level
-    raw.w[0] = f32[(size_t)(2u * g) * B + p];
-    raw.w[1] = f32[(size_t)(2u * g + 1u) * B + p];
-    raw.w[2] = f32[(size_t)(8u + 2u * g) * B + p];
-    raw.w[3] = f32[(size_t)(9u + 2u * g) * B + p];
+    const uint32_t *f32 = reinterpret_cast<const uint32_t *>(feat);
+    const size_t i = feat16_lane_index(B, p, g);
+    raw.w[0] = f32[i];
+    raw.w[1] = f32[i + B];
+    raw.w[2] = f32[i + (size_t)B * 8u];
+    raw.w[3] = f32[i + (size_t)B * 9u];
+}
+__device__ __forceinline__ void store_feat16(uint16_t *__restrict__ dfeat, uint32_t B, uint32_t p, uint32_t g, const uint4 &v) {
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dfeat);
+    const size_t i = feat16_lane_index(B, p, g);
+    d32[i] = v.x;
+    d32[i + B] = v.y;
+    d32[i + (size_t)B * 8u] = v.z;
+    d32[i + (size_t)B * 9u] = v.w;
 }
 __device__ __forceinline__ bf16x8 feat16_operand(const Feat16Raw &raw) {
     const uint4 v = make_uint4(raw.w[0], raw.w[1], raw.w[2], raw.w[3]);
@@ -177,11 +240,13 @@ __device__ __forceinline__ i16x4v tr16_get(const unsigned char *img, uint32_t la
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4v *)(img + row * 64u + 8u * (chunk ^ ((row >> 1) & 7u))));
 }
 __device__ __forceinline__ f32x4v mma16k16(i16x4v a, i16x4v b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float sum_bf16x4(i16x4v v) {
-    float s = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s += __uint_as_float((uint32_t)(uint16_t)v[j] << 16);
-    return s;
+// acc + the four bf16 values of an operand fragment: two v_dot2c_f32_bf16 against (1, 1) instead of four unpacks and four adds
+__device__ __forceinline__ float add_bf16x4(float acc, i16x4v v) {
+    const uint2 w = __builtin_bit_cast(uint2, v);
+    const uint32_t ones = 0x3f803f80u;
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w.x), "v"(ones));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w.y), "v"(ones));
+    return acc;
 }
 // derivative mask taken from the PACKED activation (its sign survives the bf16 rounding): the fp32 copies of h1 / h2 need
 // not stay live through the backward chain.  `half` selects elements 0..3 or 4..7 of the operand.
@@ -189,10 +254,12 @@ __device__ __forceinline__ f32x4v leaky_grad4_packed(const f32x4v &d, const bf16
     const uint4 w = __builtin_bit_cast(uint4, hf);
     const uint32_t w0 = half ? w.z : w.x, w1 = half ? w.w : w.y;
     f32x4v g;
+    // the odd element sits in the high half: it is positive exactly when the whole word, read as a signed integer, exceeds 0xffff
+    // (sign clear, high half non-zero) -- one compare instead of a mask and a compare
     g[0] = d[0] * (__uint_as_float(w0 << 16) > 0.0f ? 1.0f : kLeaky);
-    g[1] = d[1] * (__uint_as_float(w0 & 0xffff0000u) > 0.0f ? 1.0f : kLeaky);
+    g[1] = d[1] * ((int32_t)w0 > 0xffff ? 1.0f : kLeaky);
     g[2] = d[2] * (__uint_as_float(w1 << 16) > 0.0f ? 1.0f : kLeaky);
-    g[3] = d[3] * (__uint_as_float(w1 & 0xffff0000u) > 0.0f ? 1.0f : kLeaky);
+    g[3] = d[3] * ((int32_t)w1 > 0xffff ? 1.0f : kLeaky);
     return g;
 }
 __device__ __forceinline__ f32x4v leaky_grad4(const f32x4v &d, const f32x4v &h) {

@@ -235,6 +235,8 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
         Feat16Raw ahead;                                     // features of the next tile, in flight during this one
         if (wave < n_items) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
         Mlp16Shared::build<4>(smem, mlp);                    // after the first feature request: the two round trips overlap
+        Mlp16InRegs wt;
+        wt.load(smem, lane);
         for (uint32_t r = wave; r < n_items; r += n_waves) {
             const float *ray = src.rays + (size_t)r * 8;
             const float near = ray[6], far = ray[7];
@@ -251,7 +253,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
                     const uint32_t sn = more ? s + 16u : c;
                     load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
                 }
-                const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(now), a);
+                const float z4 = mlp16_tile_forward(wt, feat16_operand(now), a);
                 const float sigma = last_act(act, z4);
                 const float term = !valid ? 0.0f
                                  : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
@@ -265,6 +267,8 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
         }
     } else {
         Mlp16Shared::build<4>(smem, mlp);
+        Mlp16InRegs wt;
+        wt.load(smem, lane);
         const uint32_t tiles = (n_items + 15u) / 16u;
         for (uint32_t k = wave; k < tiles; k += n_waves) {
             const uint32_t p0 = 16u * k + c;
@@ -272,7 +276,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             const uint32_t p = valid ? p0 : n_items - 1u;
             Feat16Raw raw;
             load_feat16(feat, B, p, g, raw);
-            const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(raw), a);
+            const float z4 = mlp16_tile_forward(wt, feat16_operand(raw), a);
             if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
         }
     }
@@ -643,7 +647,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
                 dW2[o][1] = mma16k16(gA[o], xB[1], dW2[o][1]);
                 dW2[o][2] = mma16k16(gA[o], hB[0], dW2[o][2]);
                 dW2[o][3] = mma16k16(gA[o], hB[1], dW2[o][3]);
-                db[2][o] += sum_bf16x4(gA[o]);
+                db[2][o] = add_bf16x4(db[2][o], gA[o]);
             }
             wave_lds_fence<PrecBF16>();
 
@@ -664,7 +668,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             for (int o = 0; o < 2; ++o) {
                 dW1[o][0] = mma16k16(gA[o], hB[0], dW1[o][0]);
                 dW1[o][1] = mma16k16(gA[o], hB[1], dW1[o][1]);
-                db[1][o] += sum_bf16x4(gA[o]);
+                db[1][o] = add_bf16x4(db[1][o], gA[o]);
             }
             wave_lds_fence<PrecBF16>();
 
@@ -681,7 +685,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             for (int o = 0; o < 2; ++o) {
                 dW0[o][0] = mma16k16(gA[o], xB[0], dW0[o][0]);
                 dW0[o][1] = mma16k16(gA[o], xB[1], dW0[o][1]);
-                db[0][o] += sum_bf16x4(gA[o]);
+                db[0][o] = add_bf16x4(db[0][o], gA[o]);
             }
             wave_lds_fence<PrecBF16>();
 
@@ -690,12 +694,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dmax = max(dmax, max(__float_as_uint(dxlo[j]) & 0x7fffffffu, __float_as_uint(dxhi[j]) & 0x7fffffffu));
-                const uint4 o4 = __builtin_bit_cast(uint4, pack16(dxlo, dxhi));
-                uint32_t *df = reinterpret_cast<uint32_t *>(dfeat);
-                df[(size_t)(2u * g) * B + p] = o4.x;
-                df[(size_t)(2u * g + 1u) * B + p] = o4.y;
-                df[(size_t)(8u + 2u * g) * B + p] = o4.z;
-                df[(size_t)(9u + 2u * g) * B + p] = o4.w;
+                store_feat16(dfeat, B, p, g, __builtin_bit_cast(uint4, pack16(dxlo, dxhi)));
             }
         }
     }
