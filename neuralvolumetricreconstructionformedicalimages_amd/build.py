@@ -18,6 +18,10 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnaf_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# Per-source additions.  render_fused.hip (MLP + scatter kernels): the SLP vectoriser pairs neighbouring fp32 multiplies / adds into
+# v_pk_*_f32, which cost more issue time beside MFMAs than the two scalar instructions they replace (MI355X_MICROARCH.md, "price of one
+# filler beside MFMAs"); same-box A/B at 1 024 rays: 0.272 -> 0.268 ms per step, MLP backward at 65 536 rays 0.687 -> 0.677 ms.
+EXTRA_FLAGS = {"render_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -66,7 +70,7 @@ def build_library(force=False, verbose=False, jobs=None):
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

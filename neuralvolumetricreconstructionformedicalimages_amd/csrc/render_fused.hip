@@ -254,7 +254,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
                     load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
                 }
                 const float z4 = mlp16_tile_forward(wt, feat16_operand(now), a);
-                const float sigma = last_act(act, z4);
+                const float sigma = last_act16(act, z4);
                 const float term = !valid ? 0.0f
                                  : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
                 if (sigma_out != nullptr || depth_out != nullptr)          // per-sample outputs (wave-uniform test)
@@ -277,7 +277,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             Feat16Raw raw;
             load_feat16(feat, B, p, g, raw);
             const float z4 = mlp16_tile_forward(wt, feat16_operand(raw), a);
-            if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
+            if (valid && g == 0u) out[omap.at(p)] = last_act16(act, z4);
         }
     }
 }
@@ -321,7 +321,7 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
                 const Feat16Raw f = gather_point_features<TT>(recs, g, x, table, table_rows);
                 if (feat != nullptr && valid) store_point_features(feat, B, r * S + s, g, f);
                 const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(f), a);
-                const float sigma = last_act(act, z4);
+                const float sigma = last_act16(act, z4);
                 const float term = !valid ? 0.0f
                                  : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
                 if (sigma_out != nullptr || depth_out != nullptr)          // per-sample outputs (wave-uniform test)
@@ -343,7 +343,7 @@ fused_forward_kernel(Src src, const typename TT::store_t *__restrict__ table, co
             const Feat16Raw f = gather_point_features<TT>(recs, g, x, table, table_rows);
             if (feat != nullptr && valid) store_point_features(feat, B, p, g, f);
             const float z4 = mlp16_tile_forward(smem, lane, feat16_operand(f), a);
-            if (valid && g == 0u) out[omap.at(p)] = last_act(act, z4);
+            if (valid && g == 0u) out[omap.at(p)] = last_act16(act, z4);
         }
     }
 }
@@ -616,7 +616,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
             const unsigned char *wsh = smem + tile_tag;
             Act16 a;
             const float z4 = mlp16_tile_forward(wsh, lane, x0f, a);
-            const float sigma = last_act(act, z4);
+            const float sigma = last_act16(act, z4);
             const float gsig = !valid ? 0.0f
                              : dacc * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
             const float g4 = gsig * last_act_grad(act, z4, sigma);
