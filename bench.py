@@ -177,8 +177,7 @@ class StepFeed:
         if self.ready != i:                                            # first step of a loop: draw it now
             self.sampler.draw(i, self.n, self.rays[cur], self.target[cur])
         nxt = self.sampler.plan(i + 1, self.n, self.rays[cur ^ 1], self.target[cur ^ 1])
-        # (engines built with pipeline_levels: the next step's base makes the step a software pipeline across steps)
-        loss = engine.train_step(self.rays[cur], self.target[cur], weight, ray_base=ray_base, next_draw=nxt, next_ray_base=ray_base + self.n)
+        loss = engine.train_step(self.rays[cur], self.target[cur], weight, ray_base=ray_base, next_draw=nxt)
         self.ready = i + 1 if nxt is not None else None
         return loss
 
@@ -401,9 +400,6 @@ def main():
                          "replicated Adam; auto = whichever puts fewer bytes on the links (levels below ~3 300 rays per GPU).  Default sharded: the "
                          "level-parallel step stays opt-in until it has run over RCCL on more than one rank (DESIGN.md section 6)")
     ap.add_argument("--buckets", default=None, help="level buckets of the data-parallel exchange, e.g. 8-16,0-8 (default: dist.default_bucket_levels -- one range below 2^20 points per step)")
-    ap.add_argument("--pipeline-levels", default=None,
-                    help="A/B: BEGIN-END, e.g. 8-16: steps as a software pipeline across steps (naf_render_train_adam_pipelined: those levels are "
-                         "finished first and gathered for the next step on a side stream beside the rest of the reducer); N = 1 only")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ray batch is pipelined over (engine n_streams)")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="rays per pipelined chunk when --streams > 1")
     args = ap.parse_args()
@@ -463,8 +459,7 @@ def main():
                                  cfg_flags=args.cfg_flags | (_abi.CFG_PER_LEVEL_LAUNCHES if args.per_level else 0) | (_abi.CFG_LEVELS_INTERLEAVED if args.interleaved_levels else 0)
                                            | (_abi.CFG_ENCODE_TWO_GATHERS if args.two_gathers else 0) | (_abi.CFG_ENCODE_WINDOWS if args.windows else 0) | (_abi.CFG_BACKWARD_ONE_WAVE_PER_SIMD if args.bwd_one_wave else 0) | {0: 0, 1: _abi.CFG_ENCODE_LEVEL_MAJOR, 2: _abi.CFG_ENCODE_GROUPS_2, 4: _abi.CFG_ENCODE_GROUPS_4, 8: _abi.CFG_ENCODE_GROUPS_2 | _abi.CFG_ENCODE_GROUPS_4}[args.encode_groups],
                                  bucket_levels=buckets, fuse_table_adam=not args.separate_adam, dp_mode=args.dp_mode,
-                                 rays_per_step_hint=args.rays,
-                                 pipeline_levels=None if args.pipeline_levels is None else tuple(int(v) for v in args.pipeline_levels.split("-")))
+                                 rays_per_step_hint=args.rays)
 
     engine = make_engine(args.precision, pg)
     n = args.rays

@@ -372,32 +372,6 @@ int naf_render_train_adam_draw(const float *rays, const float *t_rand, const flo
                                float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
                                const naf_table_adam *adam, const naf_next_draw *next, void *stream);
 
-/* The same step as a software pipeline ACROSS steps (opt-in).  The levels of the table are independent: as soon as
- * the rows of the levels [level_begin, level_end) have had their Adam update, the NEXT step's features of those levels can be
- * gathered -- its rays exist already (`next`: the draw rides in pass 1 of the scatter) -- while the reducer is still busy with the
- * other levels.  The call finishes those levels first (a reducer launch of their own), then starts the next step's encode_kernel for
- * them on `side_stream` (behind `fork_event`) beside the reducer launch of the remaining levels, and makes `stream` wait for it
- * (`join_event`) before anything enqueued later.  The features land where the next call expects them (same workspace, same n_rays);
- * that call is told so with `features_ahead` = 1 and encodes the remaining levels only.  Results are bit-identical to
- * naf_render_train_adam_draw (same kernels, same arithmetic; only the order of independent launches differs).
- *   `*encoded_ahead` (host int, written before the call returns): 1 if this call did encode the next step's levels ahead; 0 where the
- * pipeline does not apply (atomic scatter, fp32 parity mode, record buffers walked in passes, empty batches) -- the step then ran
- * exactly like naf_render_train_adam_draw, and the next call must be given features_ahead = 0.
- *   `next_ray_index_base` / `next_t_rand`: cfg->ray_index_base and t_rand of the next step (its jitter).  Events: created by the
- * caller (hipEventDisableTiming is enough); all calls of a loop must use the same `stream`. */
-typedef struct naf_step_pipeline {
-    uint32_t level_begin, level_end;
-    int32_t features_ahead;
-    uint32_t next_ray_index_base;
-    const float *next_t_rand;
-    void *side_stream, *fork_event, *join_event;
-    int32_t *encoded_ahead;
-} naf_step_pipeline;
-int naf_render_train_adam_pipelined(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
-                                    const void *embeddings, const int32_t *offsets, const float *mlp, float *acc, float *grad_embeddings,
-                                    float *grad_mlp, float *loss_out, uint32_t n_rays, const naf_render_cfg *cfg, void *workspace,
-                                    const naf_table_adam *adam, const naf_next_draw *next, const naf_step_pipeline *pipe, void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Level-parallel training for small steps on several GPUs (one process per GPU; no counterpart in the reference, which has no
  * distributed code -- it shards trainer.py:134-142 around train.py:48-135 like the data-parallel step does, with the same result).

@@ -93,16 +93,6 @@ class NextDraw(ctypes.Structure):
     ]
 
 
-class StepPipeline(ctypes.Structure):
-    """struct naf_step_pipeline (include/naf_hip.h): the software pipeline across steps of naf_render_train_adam_pipelined."""
-    _fields_ = [
-        ("level_begin", ctypes.c_uint32), ("level_end", ctypes.c_uint32), ("features_ahead", ctypes.c_int32),
-        ("next_ray_index_base", ctypes.c_uint32), ("next_t_rand", ctypes.c_void_p),
-        ("side_stream", ctypes.c_void_p), ("fork_event", ctypes.c_void_p), ("join_event", ctypes.c_void_p),
-        ("encoded_ahead", ctypes.POINTER(ctypes.c_int32)),
-    ]
-
-
 # name -> (restype, argtypes); mirrors include/naf_hip.h one to one (checked by tests/test_abi_symbols.py)
 _vp, _u32, _u64, _i32, _f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
@@ -136,8 +126,6 @@ SIGNATURES = {
                                      ctypes.POINTER(TableAdam), _vp]),
     "naf_render_train_adam_draw": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
                                           ctypes.POINTER(TableAdam), ctypes.POINTER(NextDraw), _vp]),
-    "naf_render_train_adam_pipelined": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp,
-                                               ctypes.POINTER(TableAdam), ctypes.POINTER(NextDraw), ctypes.POINTER(StepPipeline), _vp]),
     "naf_levels_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp]),
     "naf_levels_field_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _vp, _vp, _vp]),
     "naf_levels_scatter": (_i32, [_vp, _vp, _vp, ctypes.c_size_t, _u32, _vp, _vp, _u32, ctypes.POINTER(RenderCfg), _u32, _u32, _vp,

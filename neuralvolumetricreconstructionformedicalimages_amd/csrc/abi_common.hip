@@ -87,4 +87,4 @@ extern "C" int naf_profile_collect(char *buf, size_t buflen) {
 }
 
 extern "C" const char *naf_last_error(void) { return naf::g_last_error; }
-extern "C" int naf_abi_version(void) { return 6; }      // 4: naf_hash_encode_workspace_bytes / _backward_ws, NAF_CFG_SCATTER_PAIR12; 5: naf_render_train_adam_draw; 6: naf_render_train_adam_pipelined
+extern "C" int naf_abi_version(void) { return 5; }      // 4: naf_hash_encode_workspace_bytes / _backward_ws, NAF_CFG_SCATTER_PAIR12; 5: naf_render_train_adam_draw

@@ -17,7 +17,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <functional>
 #include <type_traits>
 
 #include "naf_host.h"
@@ -794,18 +793,6 @@ static uint32_t backward_lds_bytes() {
     return sh + std::max<uint32_t>(imgs + 4u * kMaxSamplesLds * 4u, (kMlpParams + 2u) * 4u);
 }
 
-// Software pipeline across steps (naf_render_train_adam_pipelined): the levels [lb, le) are reduced first and the NEXT step's features
-// of those levels are gathered on `side` beside the reducer launch of the others.  `encode_next` is bound where the precision
-// policy is known (render_train_impl); `done` reports whether the scatter route taken could honour the request.
-struct PipeCtx {
-    uint32_t lb, le;
-    bool features_ahead;
-    hipStream_t side;
-    hipEvent_t fork, join;
-    std::function<int(hipStream_t)> encode_next;
-    bool done = false;
-};
-
 struct Workspace {
     unsigned char *feat, *dfeat;
     float *slabs, *grad_acc;
@@ -1046,7 +1033,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
                                const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
-                               DrawJob *next_draw = nullptr, PipeCtx *pipe = nullptr) {
+                               DrawJob *next_draw = nullptr) {
 #ifndef NAF_V2_LV_FEW
 #define NAF_V2_LV_FEW 4u      // levels per bin workgroup when tiles are scarce.  A/B builds (tools/build_variant.sh) override it: 2 gains 2 us at
                               // 512 rays and loses 9 at 4 096, 8 the other way round (profiles/round4_ab_reducer_nt_loads_and_levels_per_bin_workgroup.jsonl)
@@ -1104,25 +1091,6 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
         }
         return NAF_OK;
     }
-    // Pipelined step: one bin pass over all levels, the levels [lb, le) finished first, then the next step's gathers of those levels on
-    // the side stream beside the reducer launch(es) of the rest.  Every partial launch must stay unsplit (one owner per row: the Adam tail).
-    if (pipe != nullptr && adam != nullptr && !per_level && lv_begin == 0u && lv_end == cfg->L && plan.levels_per_pass >= cfg->L &&
-        pipe->lb < pipe->le && pipe->le <= cfg->L && reducer_split(NB, pipe->le - pipe->lb) == 1u &&
-        (pipe->lb == 0u || reducer_split(NB, pipe->lb) == 1u) && (pipe->le == cfg->L || reducer_split(NB, cfg->L - pipe->le) == 1u)) {
-        if (int rc = launch_bin(0u, cfg->L)) return rc;              // (carries the next step's pixel draw: its rays exist from here on)
-        if (int rc = launch_reduce(0u, pipe->lb, pipe->le - pipe->lb)) return rc;
-        if (hipEventRecord(pipe->fork, s) != hipSuccess || hipStreamWaitEvent(pipe->side, pipe->fork, 0) != hipSuccess)
-            return fail(NAF_ERR_LAUNCH, "pipelined step: cannot fork the side stream");
-        if (int rc = pipe->encode_next(pipe->side)) return rc;
-        if (hipEventRecord(pipe->join, pipe->side) != hipSuccess) return fail(NAF_ERR_LAUNCH, "pipelined step: cannot record the join event");
-        if (pipe->lb != 0u)
-            if (int rc = launch_reduce(0u, 0u, pipe->lb)) return rc;
-        if (pipe->le != cfg->L)
-            if (int rc = launch_reduce(0u, pipe->le, cfg->L - pipe->le)) return rc;
-        if (hipStreamWaitEvent(s, pipe->join, 0) != hipSuccess) return fail(NAF_ERR_LAUNCH, "pipelined step: cannot join the side stream");
-        pipe->done = true;
-        return NAF_OK;
-    }
     for (uint32_t l0 = lv_begin; l0 < lv_end; l0 += plan.levels_per_pass) {
         const uint32_t nl = std::min(plan.levels_per_pass, lv_end - l0);
         if (int rc = launch_bin(l0, nl)) return rc;
@@ -1136,10 +1104,10 @@ template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                     const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
                                     const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
-                                    DrawJob *next_draw = nullptr, PipeCtx *pipe = nullptr) {
+                                    DrawJob *next_draw = nullptr) {
     using FT = typename P::feat_t;
     if (w.binned) {
-        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job, next_draw, pipe);
+        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job, next_draw);
         if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
         return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
     }
@@ -1164,9 +1132,9 @@ static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const
 template <typename P, uint32_t C>
 static int run_hash_backward(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                              const naf_render_cfg *cfg, const Workspace &w, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr, DrawJob *next_draw = nullptr, PipeCtx *pipe = nullptr) {
+                             const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr, DrawJob *next_draw = nullptr) {
     // (the overflow counters were zeroed by the MLP backward kernel of this call: StepExtras)
-    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam, slab_job, next_draw, pipe);
+    if (buckets == nullptr) return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, nullptr, adam, slab_job, next_draw);
     if (adam != nullptr) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train: the Adam tail cannot be combined with gradient buckets");
     if (w.binned && !per_level_launches(cfg) && w.plan.levels_per_pass >= cfg->L)      // one bin pass, per-bucket reduction + events
         return run_hash_backward_levels<P, C>(src, dfeat, offsets, grad_table, B, cfg, w, 0u, cfg->L, s, buckets);
@@ -1229,17 +1197,11 @@ static int run_fused_forward(const Src &src, const void *table, const int32_t *o
 template <typename P, uint32_t C>
 static int render_forward_impl(const float *rays, const float *t_rand, const void *emb, const int32_t *offsets, const float *mlp,
                                float *acc, uint32_t n_rays, const naf_render_cfg *cfg, void *ws, hipStream_t s,
-                               float *sigma_out = nullptr, float *depth_out = nullptr, bool keep_features = false, const PipeCtx *pipe = nullptr) {
+                               float *sigma_out = nullptr, float *depth_out = nullptr, bool keep_features = false) {
     const uint32_t B = n_rays * cfg->n_samples;
     const SrcRays src = make_src(rays, t_rand, cfg);
     if (forward_fused(cfg) && !keep_features)              // a training step needs the features for its backward pass
         return run_fused_forward(src, emb, offsets, mlp, acc, sigma_out, depth_out, ws, n_rays, B, cfg, OutMap{0u, 0u, 0u, 0u}, s);
-    if (pipe != nullptr && pipe->features_ahead) {         // the previous pipelined call gathered the levels [lb, le) of these rays already
-        if (pipe->lb != 0u)
-            if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s, 0u, pipe->lb)) return rc;
-        if (pipe->le < cfg->L)
-            if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s, pipe->le, cfg->L)) return rc;
-    } else
     if (int rc = dispatch_encode<P, C>(src, emb, offsets, ws, B, cfg, s)) return rc;        // the features sit at the workspace base
     return run_mlp_forward<P, C, true>(ws, mlp, src, acc, n_rays, B, cfg, s, sigma_out, depth_out);
 }
@@ -1249,8 +1211,7 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
                                 const float *mlp, float *grad_emb, float *grad_mlp, uint32_t n_rays, const naf_render_cfg *cfg,
                                 void *ws, int features_valid, const naf_grad_buckets *buckets, hipStream_t s,
                                 const AdamTail *adam = nullptr, bool from_train = false, const LossInputs &loss = LossInputs{nullptr, nullptr, nullptr},
-                                float *loss_out = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr,
-                                PipeCtx *pipe = nullptr) {
+                                float *loss_out = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
     const uint32_t B = n_rays * cfg->n_samples;
     const Workspace w = carve(ws, cfg, B);
     const SrcRays src = make_src(rays, t_rand, cfg);
@@ -1274,29 +1235,20 @@ static int render_backward_impl(const float *rays, const float *t_rand, const fl
     // grad_mlp (and, in the training entry point, the loss) are final here, before the table scatter starts
     if (buckets != nullptr && buckets->mlp_ready != nullptr && hipEventRecord((hipEvent_t)buckets->mlp_ready, s) != hipSuccess)
         return fail(NAF_ERR_LAUNCH, "render_train: cannot record the MLP-gradient event");
-    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, defer ? &job : nullptr, next_draw, pipe);
+    return run_hash_backward<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, buckets, s, adam, defer ? &job : nullptr, next_draw);
 }
 
 template <typename P, uint32_t C>
 static int render_train_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight, const void *emb,
                              const int32_t *offsets, const float *mlp, float *acc, float *grad_emb, float *grad_mlp, float *loss_out,
                              uint32_t n_rays, const naf_render_cfg *cfg, void *ws, const naf_grad_buckets *buckets, hipStream_t s,
-                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr,
-                             PipeCtx *pipe = nullptr, const naf_step_pipeline *pipe_args = nullptr) {
-    naf_render_cfg next_cfg = *cfg;
-    if (pipe != nullptr && next_draw != nullptr) {           // the next step's gathers of the levels this step finishes first
-        next_cfg.ray_index_base = pipe_args->next_ray_index_base;
-        const SrcRays next_src = make_src(next_draw->rays, pipe_args->next_t_rand, &next_cfg);
-        const uint32_t B = n_rays * cfg->n_samples, lb = pipe->lb, le = pipe->le;
-        const naf_render_cfg *nc = &next_cfg;
-        pipe->encode_next = [=](hipStream_t side) { return dispatch_encode<P, C>(next_src, emb, offsets, ws, B, nc, side, lb, le); };
-    }
-    if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true, pipe)) return rc;
+                             const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
+    if (int rc = render_forward_impl<P, C>(rays, t_rand, emb, offsets, mlp, acc, n_rays, cfg, ws, s, nullptr, nullptr, true)) return rc;
     // the masked squared error and its gradient are formed inside the backward kernel (LossInputs); the loss reaches loss_out
     // through the slab reduction that also finishes the MLP gradient
     const LossInputs loss{acc, target, ray_weight};
     return render_backward_impl<P, C>(rays, t_rand, nullptr, emb, offsets, mlp, grad_emb, grad_mlp, n_rays, cfg, ws, 1, buckets, s, adam, true,
-                                      loss, loss_out, madam, loss_assign, next_draw, pipe);
+                                      loss, loss_out, madam, loss_assign, next_draw);
 }
 
 template <typename P, uint32_t C>
@@ -1553,8 +1505,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
                               const naf_render_cfg *cfg, void *workspace, const naf_grad_buckets *buckets, void *stream,
-                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr,
-                              PipeCtx *pipe = nullptr, const naf_step_pipeline *pipe_args = nullptr) {
+                              const AdamTail *adam = nullptr, const MlpAdam *madam = nullptr, bool loss_assign = false, DrawJob *next_draw = nullptr) {
     if (int rc = check_cfg(cfg, "render_train")) return rc;
     if (int rc = check_depths(cfg, t_rand)) return rc;
     if (n_rays != 0 && (!rays || !target || !ray_weight || !embeddings || !offsets || !mlp || !acc || !grad_embeddings || !grad_mlp || !workspace))
@@ -1573,7 +1524,7 @@ static int render_train_entry(const float *rays, const float *t_rand, const floa
         return NAF_OK;
     }
     NAF_DISPATCH_PC(render_train_impl, rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp,
-                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam, loss_assign, next_draw, pipe, pipe_args);
+                    loss_out, n_rays, cfg, workspace, buckets, (hipStream_t)stream, adam, madam, loss_assign, next_draw);
 }
 
 extern "C" int naf_render_train(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
@@ -1598,8 +1549,7 @@ static_assert(kAdamLpF16 == NAF_F16 && kAdamLpBF16 == NAF_BF16, "adam_math.h mir
 static int render_train_adam_impl(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
                                   const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
                                   float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                                  const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream, DrawJob *next_draw,
-                                  PipeCtx *pipe = nullptr, const naf_step_pipeline *pipe_args = nullptr) {
+                                  const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam, void *stream, DrawJob *next_draw) {
     if (!adam) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null adam");
     if (!adam->param || !adam->exp_avg || !adam->exp_avg_sq || !grad_embeddings) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: null pointer");
     if (adam->step == 0) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam: step is 1-based");
@@ -1624,7 +1574,7 @@ static int render_train_adam_impl(const float *rays, const float *t_rand, const 
     const uint64_t n_points = (uint64_t)n_rays * cfg->n_samples;
     if (n_rays != 0 && workspace != nullptr && n_points < (1ull << 31) && adam_tail_possible(cfg, carve(workspace, cfg, n_points)))
         return render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
-                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp, true, next_draw, pipe, pipe_args);
+                                  n_rays, cfg, workspace, nullptr, stream, &tail, mp, true, next_draw);
     // small batches (atomic scatter), split reducer launches, per-level diagnostics, empty batches: the two passes one after the other
     if (int rc = render_train_entry(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out,
                                     n_rays, cfg, workspace, nullptr, stream, nullptr, mp, true)) return rc;
@@ -1658,37 +1608,6 @@ extern "C" int naf_render_train_adam_draw(const float *rays, const float *t_rand
                                next->far, next->parallel, next->seed, &job)) return rc;
     if (int rc = render_train_adam_impl(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out, n_rays,
                                         cfg, workspace, adam, stream, &job)) return rc;
-    return launch_draw(job, (hipStream_t)stream);            // count == 0 when pass 1 took it along
-}
-
-// ... and as a software pipeline across steps (naf_hip.h): the next step's gathers of the levels this step finishes first run on a side
-// stream beside the rest of the reducer.
-extern "C" int naf_render_train_adam_pipelined(const float *rays, const float *t_rand, const float *target, const float *ray_weight,
-                                               const void *embeddings, const int32_t *offsets, const float *mlp, float *acc,
-                                               float *grad_embeddings, float *grad_mlp, float *loss_out, uint32_t n_rays,
-                                               const naf_render_cfg *cfg, void *workspace, const naf_table_adam *adam,
-                                               const naf_next_draw *next, const naf_step_pipeline *pipe, void *stream) {
-    if (!pipe || !next) return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: null pipe / next");
-    if (!pipe->encoded_ahead || !pipe->side_stream || !pipe->fork_event || !pipe->join_event || pipe->side_stream == stream)
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: side stream (not the launch stream), both events and encoded_ahead are required");
-    *pipe->encoded_ahead = 0;
-    if (!cfg || pipe->level_begin >= pipe->level_end || pipe->level_end > cfg->L)
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: empty or out-of-range level range");
-    if (next->n_draws != n_rays || next->rays == nullptr)
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: the next step must have this step's ray count");
-    if (next->rays == rays || (next->target != nullptr && next->target == target))
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: the next step's rays / targets must not be the buffers this step reads");
-    if ((cfg->flags & NAF_CFG_EXPLICIT_DEPTHS) != 0u && pipe->next_t_rand == nullptr)
-        return fail(NAF_ERR_INVALID_ARGUMENT, "render_train_adam_pipelined: explicit depths need next_t_rand");
-    DrawJob job;
-    if (int rc = make_draw_job(&next->draw, next->poses, next->projections, next->pixels, next->target, next->rays, next->first_draw, next->n_draws,
-                               next->n_projections, next->det_w, next->det_h, next->du, next->dv, next->ou, next->ov, next->DSD, next->near,
-                               next->far, next->parallel, next->seed, &job)) return rc;
-    PipeCtx ctx{pipe->level_begin, pipe->level_end, pipe->features_ahead != 0, (hipStream_t)pipe->side_stream, (hipEvent_t)pipe->fork_event,
-                (hipEvent_t)pipe->join_event, {}, false};
-    if (int rc = render_train_adam_impl(rays, t_rand, target, ray_weight, embeddings, offsets, mlp, acc, grad_embeddings, grad_mlp, loss_out, n_rays,
-                                        cfg, workspace, adam, stream, &job, &ctx, pipe)) return rc;
-    *pipe->encoded_ahead = ctx.done ? 1 : 0;
     return launch_draw(job, (hipStream_t)stream);            // count == 0 when pass 1 took it along
 }
 

@@ -25,7 +25,7 @@ from . import fused
 class NAFEngine:
     def __init__(self, net, n_samples, perturb=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, table_dtype=torch.float32,
                  mlp_precision=None, seed=0, process_group=None, n_streams=1, chunk_rays=16384, scatter_mode=None, cfg_flags=None,
-                 bucket_levels=None, fuse_table_adam=True, dp_mode="sharded", rays_per_step_hint=None, pipeline_levels=None):
+                 bucket_levels=None, fuse_table_adam=True, dp_mode="sharded", rays_per_step_hint=None):
         if not net.fused_supported():
             raise RuntimeError("NAFEngine needs the canonical NAF network (in 32, hidden 32, 4 layers, skips=[2], out 1)")
         self.net = net
@@ -59,10 +59,6 @@ class NAFEngine:
         # single-GPU, single-stream steps let the gradient reducer apply the table's Adam update itself (naf_render_train_adam:
         # the gradient table is neither written, re-read nor cleared; bit-identical to backward() + optimizer_step())
         self.fuse_table_adam = bool(fuse_table_adam)
-        # opt-in: steps as a software pipeline across steps (train_step(next_draw=..., next_ray_base=...)): the levels [begin, end) are
-        # finished first and gathered for the next step beside the rest of the reducer (naf_render_train_adam_pipelined)
-        self.pipeline_levels = None if pipeline_levels is None else (int(pipeline_levels[0]), int(pipeline_levels[1]))
-        self._pipe_side, self._pipe_events, self._ahead = None, None, None
 
         # ---- flat fp32 master parameters; module parameters become views ---------------------------------
         # The table lives in a flat buffer whose length is rounded up to `pad_to` elements: the exchange ranges of a data-parallel
@@ -645,16 +641,13 @@ class NAFEngine:
         return z
 
     def train_step(self, rays, target, weight, t_rand=None, ray_base=0, raw_noise_std=0.0, noise=None, rays_all=None, global_ray_base=None,
-                   next_draw=None, next_ray_base=None):
+                   next_draw=None):
         """One optimisation step on `rays` [n,8]; loss = sum_r weight[r] (acc[r]-target[r])^2.  Returns the loss tensor
         (device, no sync).  `raw_noise_std` > 0 (render.py:196-199): the per-sample noise on sigma adds sum_s noise_s * dist_s to a
         ray's line integral and nothing else (render.noise_line_integral), so the step runs on target - that term; `noise`: explicit
         N(0, 1) draws [n, S] instead of torch.randn.  `rays_all` / `global_ray_base`: level-parallel steps only (_train_step_levels).
         `next_draw` (`RayGenerator.plan_draw`): the pixel draw of the NEXT step, carried along by this one (naf_render_train_adam_draw:
-        spare workgroups of the scatter's first launch on the fused single-GPU path, a launch of its own behind the step otherwise).
-        `next_ray_base` (with `next_draw`, engines built with `pipeline_levels=(begin, end)`): `ray_base` of the next step -- the step
-        then runs as a software pipeline across steps (naf_render_train_adam_pipelined): the next step's gathers of those levels
-        start beside the rest of this step's reducer; same results."""
+        spare workgroups of the scatter's first launch on the fused single-GPU path, a launch of its own behind the step otherwise)."""
         n = rays.shape[0]
         if float(raw_noise_std) > 0.0 and n > 0:
             from .render import noise_line_integral
@@ -662,7 +655,7 @@ class NAFEngine:
         if self.dp_mode == "levels" and self.process_group is not None:
             self._train_step_levels(rays, target, weight, t_rand, ray_base, rays_all, global_ray_base)
         elif self.fuse_table_adam and self._dp is None and (self.n_streams == 1 or n <= self.chunk_rays) and n > 0:
-            self._train_step_fused_adam(rays, target, weight, t_rand, ray_base, next_draw, next_ray_base)
+            self._train_step_fused_adam(rays, target, weight, t_rand, ray_base, next_draw)
             next_draw = None
         else:
             self.backward(rays, target, weight, t_rand, ray_base)
@@ -677,7 +670,7 @@ class NAFEngine:
         self.rays_seen += n
         return self.loss
 
-    def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base, next_draw=None, next_ray_base=None):
+    def _train_step_fused_adam(self, rays, target, weight, t_rand, ray_base, next_draw=None):
         """backward() + optimizer_step() in ONE library call: naf_render_train_adam -- the gradient reducer finishes every table
         row with its Adam update, the slab reduction of the MLP gradient does the same for the 4 225 MLP parameters."""
         n = rays.shape[0]
@@ -696,31 +689,8 @@ class NAFEngine:
         args = (_abi.ptr(rays), _abi.ptr(t_rand), _abi.ptr(target), _abi.ptr(weight), _abi.ptr(self.table), _abi.ptr(self.offsets),
                 _abi.ptr(self.mlp), _abi.ptr(self.acc), _abi.ptr(self.emb_g), _abi.ptr(self.mlp_g), _abi.ptr(self.loss), n,
                 ctypes.byref(cfg), _abi.ptr(ws), ctypes.byref(st))
-        pipelined = (self.pipeline_levels is not None and next_draw is not None and next_ray_base is not None and t_rand is None
-                     and int(next_draw.n_draws) == n)
-        ahead = self._ahead
-        self._ahead = None                                     # whatever happens below, the features gathered ahead are spent
         if next_draw is None:
             _abi.check(_abi.lib().naf_render_train_adam(*args, _abi.stream_ptr()), "render_train_adam")
-        elif pipelined:
-            if self._pipe_side is None:
-                self._pipe_side = torch.cuda.Stream(device=self.device)
-                self._pipe_events = (torch.cuda.Event(), torch.cuda.Event())
-                for e in self._pipe_events:                    # torch creates the HIP event lazily: record once so that the handle exists
-                    e.record()
-            key = (rays.data_ptr(), n, int(ray_base), ws.data_ptr(), _abi.stream_ptr())
-            pp = _abi.StepPipeline()
-            pp.level_begin, pp.level_end = self.pipeline_levels
-            pp.features_ahead = 1 if ahead == key else 0
-            pp.next_ray_index_base, pp.next_t_rand = int(next_ray_base) & 0xFFFFFFFF, None
-            pp.side_stream = self._pipe_side.cuda_stream
-            pp.fork_event, pp.join_event = (e.cuda_event for e in self._pipe_events)
-            done = ctypes.c_int32(0)
-            pp.encoded_ahead = ctypes.pointer(done)
-            _abi.check(_abi.lib().naf_render_train_adam_pipelined(*args, ctypes.byref(next_draw), ctypes.byref(pp), _abi.stream_ptr()),
-                       "render_train_adam_pipelined")
-            if done.value:                                     # what the next call must look like for its features to be the ones gathered
-                self._ahead = (int(next_draw.rays), n, int(next_ray_base), ws.data_ptr(), _abi.stream_ptr())
         else:
             _abi.check(_abi.lib().naf_render_train_adam_draw(*args, ctypes.byref(next_draw), _abi.stream_ptr()), "render_train_adam_draw")
         fused._bump(self.device)                               # (the MLP's update rode on the slab reduction of that call)

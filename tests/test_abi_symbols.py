@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_abi.SIGNATURES) == _declared()
-    assert _abi.lib().naf_abi_version() == 6
+    assert _abi.lib().naf_abi_version() == 5
     assert _abi.lib().naf_last_error() is not None
 
 

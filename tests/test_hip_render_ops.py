@@ -225,67 +225,3 @@ def test_a_step_can_carry_the_pixel_draw_of_the_next_one(table):
     plan = gen.plan_draw([valid[0]], n, 1, projs, rays_a, tgt_a)
     with pytest.raises(RuntimeError, match="must not be the buffers"):
         a.train_step(rays_a, tgt_a, weight, ray_base=0, next_draw=plan)
-
-
-@pytest.mark.parametrize("levels", [(8, 16), (4, 12), (0, 8)])
-def test_steps_as_a_pipeline_across_steps_equal_plain_steps(levels):
-    """naf_render_train_adam_pipelined: step k finishes the rows of `levels` first and gathers step k + 1's features of those levels on
-    a side stream beside the rest of its reducer; step k + 1 encodes the remaining levels only.  Same kernels, same arithmetic:
-    parameters, moments, loss and line integrals are bit-identical to plain steps on the same draws -- also when a step in the middle
-    of the loop is not pipelined (a batch on the atomic scatter) and when the caller's next step is not the one announced."""
-    from neuralvolumetricreconstructionformedicalimages_amd import phantom
-    from neuralvolumetricreconstructionformedicalimages_amd.encoder import HashEncoder
-    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
-    from neuralvolumetricreconstructionformedicalimages_amd.geometry import ConeGeometry, RayGenerator
-    from neuralvolumetricreconstructionformedicalimages_amd.network import DensityNetwork
-    dev = torch.device("cuda")
-    geo = ConeGeometry(phantom.scan_geometry(16, "cone"))                    # 32 x 32 detector
-    gen = RayGenerator(geo, np.linspace(0, np.pi, 7)[:-1], dev)
-    hw = gen.pixels_per_projection
-    g = torch.Generator().manual_seed(3)
-    projs = torch.rand(6 * hw, generator=g) * 0.2
-    projs[torch.rand(6 * hw, generator=g) < 0.3] = 0.0
-    projs = projs.cuda()
-    valid = [(torch.nonzero(projs[i * hw:(i + 1) * hw] > 0).reshape(-1) + i * hw).contiguous() for i in range(6)]
-    S, n = 192, 96
-
-    def engine(**kw):
-        torch.manual_seed(0)
-        net = DensityNetwork(HashEncoder(3, 16, 2, 16, 15), bound=0.3, num_layers=4, hidden_dim=32, skips=[2], out_dim=1,
-                             last_activation="sigmoid").to(dev)
-        return NAFEngine(net, S, perturb=True, lr=1e-2, table_dtype=torch.bfloat16, seed=5, **kw)
-
-    a, b = engine(), engine(pipeline_levels=levels)
-    weight = torch.full((n,), 1.0 / n, device=dev)
-    rays_a, tgt_a = torch.empty(n, 8, device=dev), torch.empty(n, device=dev)
-    rays_b = [torch.empty(n, 8, device=dev) for _ in range(2)]
-    tgt_b = [torch.empty(n, device=dev) for _ in range(2)]
-    gen.draw([valid[0]], n, seed=100, projections=projs, rays_out=rays_b[0], target_out=tgt_b[0], want_pixels=False)
-    ahead_seen = 0
-    for k in range(8):
-        gen.draw([valid[k % 6]], n, seed=100 + k, projections=projs, rays_out=rays_a, target_out=tgt_a, want_pixels=False)
-        a.train_step(rays_a, tgt_a, weight, ray_base=k * n)
-        cur = k & 1
-        plan = gen.plan_draw([valid[(k + 1) % 6]], n, 100 + k + 1, projs, rays_b[cur ^ 1], tgt_b[cur ^ 1])
-        # step 4 announces a wrong base for step 5: the features gathered ahead then do not belong to step 5's jitter and must not be used
-        nxt_base = (k + 1) * n if k != 4 else 12345
-        ahead_seen += b._ahead is not None
-        b.train_step(rays_b[cur], tgt_b[cur], weight, ray_base=k * n, next_draw=plan, next_ray_base=nxt_base)
-        assert torch.equal(a.acc[:n], b.acc[:n]) and torch.equal(a.loss, b.loss), f"step {k}"
-        assert torch.equal(a.emb, b.emb) and torch.equal(a.mlp, b.mlp), f"step {k}"
-    torch.cuda.synchronize()
-    assert ahead_seen >= 6                                                   # the pipeline did run (every step but the first found features)
-    assert torch.equal(a.emb_m, b.emb_m) and torch.equal(a.emb_v, b.emb_v) and torch.equal(a.table, b.table)
-    # a batch on the atomic scatter is not pipelined; the call says so and the loop carries on
-    m = 16
-    w2 = torch.full((m,), 1.0 / m, device=dev)
-    r2 = [torch.empty(m, 8, device=dev) for _ in range(2)]
-    t2 = [torch.empty(m, device=dev) for _ in range(2)]
-    gen.draw([valid[0]], m, seed=300, projections=projs, rays_out=r2[0], target_out=t2[0], want_pixels=False)
-    for k in range(2):
-        cur = k & 1
-        plan = gen.plan_draw([valid[(k + 1) % 6]], m, 300 + k + 1, projs, r2[cur ^ 1], t2[cur ^ 1])
-        b.train_step(r2[cur], t2[cur], w2, ray_base=k * m, next_draw=plan, next_ray_base=(k + 1) * m)
-        assert b._ahead is None
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(b.emb).all())

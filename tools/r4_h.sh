@@ -1,5 +1,5 @@
 #!/bin/bash
-# software pipeline across steps: parity test, then same-box A/B of the bench's main loop with and without it
+# (historical: the A/B of commit f5437ab, naf_render_train_adam_pipelined -- the entry point was removed afterwards; profiles/round4_ab_pipeline_across_steps.jsonl)
 mkdir -p gpurun_out/r4h
 timeout -k 10 500 python -m pytest tests/test_hip_render_ops.py tests/test_abi_symbols.py -x -q -m gpu > gpurun_out/r4h/tests.log 2>&1; rc=$?; tail -15 gpurun_out/r4h/tests.log
 [ $rc = 0 ] || exit $rc
