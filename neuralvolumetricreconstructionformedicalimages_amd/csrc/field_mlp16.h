@@ -129,12 +129,17 @@ __device__ __forceinline__ float sum_lane_groups(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// Final activation of the bf16-mode kernels.  The sigmoid takes the hardware's exp2 and reciprocal (two roundings of about one ulp
-// each, against operands that were rounded to bf16 three layers earlier) instead of expf's range reduction and an IEEE division:
-// 6 instead of 29 vector instructions per tile.  The fp32 parity mode keeps last_act.  The backward kernel recomputes sigma with
-// this same function, so forward and gradient agree.
+// Final activation of the bf16-mode kernels: last_act, the function the fp32 parity mode uses -- the bf16 mode differs from it in the
+// rounding of MFMA operands and in nothing else.  NAF_MLP16_FAST_SIGMOID (A/B builds, tools/build_variant.sh) takes the hardware's exp2
+// and reciprocal instead of expf's range reduction and an IEEE division (6 instead of 29 vector instructions per tile: forward
+// 0.249 -> 0.242 ms, backward 0.695 -> 0.677 ms at 65 536 rays, nothing measurable at 1 024).  Not the default: the change is two ulp
+// of sigma, and on the reference's 75 000-step schedule that is enough to send ONE of four seeds down another trajectory (final volume
+// PSNR of seed 0: 39.78 -> 37.77 dB, seeds 1-3 within +-0.25 dB: profiles/round4_seed_study_mlp_numerics.jsonl) -- a 2 dB lottery ticket
+// is a poor trade for 0.4 % of a large-batch step.  The backward recomputes sigma with this same function.
 __device__ __forceinline__ float last_act16(int kind, float z) {
+#ifdef NAF_MLP16_FAST_SIGMOID
     if (kind == 0) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+#endif
     return last_act(kind, z);
 }
 
@@ -257,13 +262,22 @@ __device__ __forceinline__ i16x4v tr16_get(const unsigned char *img, uint32_t la
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4v *)(img + row * 64u + 8u * (chunk ^ ((row >> 1) & 7u))));
 }
 __device__ __forceinline__ f32x4v mma16k16(i16x4v a, i16x4v b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
-// acc + the four bf16 values of an operand fragment: two v_dot2c_f32_bf16 against (1, 1) instead of four unpacks and four adds
+// acc + the four bf16 values of an operand fragment (bias gradients).  NAF_MLP16_DOT2_BIAS_SUM (A/B builds): two v_dot2c_f32_bf16
+// against (1, 1) instead of four unpacks and four adds -- 28 instructions per tile less, backward 0.703 -> 0.694 ms at 65 536 rays;
+// the sums then round in another order, which is all it takes to move seed 0's trajectory (see last_act16), so it is not the default.
 __device__ __forceinline__ float add_bf16x4(float acc, i16x4v v) {
     const uint2 w = __builtin_bit_cast(uint2, v);
+#ifdef NAF_MLP16_DOT2_BIAS_SUM
     const uint32_t ones = 0x3f803f80u;
     asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w.x), "v"(ones));
     asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w.y), "v"(ones));
     return acc;
+#else
+    float s = 0.0f;
+    s += __uint_as_float(w.x << 16); s += __uint_as_float(w.x & 0xffff0000u);
+    s += __uint_as_float(w.y << 16); s += __uint_as_float(w.y & 0xffff0000u);
+    return acc + s;
+#endif
 }
 // derivative mask taken from the PACKED activation (its sign survives the bf16 rounding): the fp32 copies of h1 / h2 need
 // not stay live through the backward chain.  `half` selects elements 0..3 or 4..7 of the operand.
