@@ -243,6 +243,44 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
             if (use_zbuf) fill_depths(src, r, near, far, zbuf, lane);
             float part = 0.0f, carry = 0.0f;
+            if (sigma_out == nullptr && depth_out == nullptr) {            // (wave-uniform) line integrals only: training, projections
+                // All four lane groups of a tile hold the same z4, so the activation and the sample distance -- 40 of a tile's ~125
+                // vector instructions -- would be evaluated four times over.  Four tiles share one evaluation instead: lane group j
+                // keeps the z4 of tile k0 + j, i.e. lane (c, g) ends up with sample 16 (k0 + g) + c.  The terms then return to lane
+                // group 0 row by row (v_permlane*_swap) and are added in tile order -- the order of the loop below: same bits.
+                for (uint32_t k0 = 0; k0 < tiles; k0 += 4u) {
+                    float zsel = 0.0f;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t k = k0 + j;
+                        if (k >= tiles) break;                               // uniform
+                        const uint32_t sk = 16u * k + c;
+                        const Feat16Raw now = ahead;
+                        {   // next tile of this ray, else first tile of this wave's next ray, else (nothing left) this tile again
+                            const bool more = k + 1u < tiles;
+                            const uint32_t rn = more ? r : (r + n_waves < n_items ? r + n_waves : r);
+                            const uint32_t sn = more ? sk + 16u : c;
+                            load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
+                        }
+                        const float z4 = mlp16_tile_forward(wt, feat16_operand(now), a);
+                        zsel = g == j ? z4 : zsel;
+                    }
+                    const uint32_t s = 16u * (k0 + g) + c;
+                    const float sigma = last_act16(act, zsel);
+                    const float term = s >= S ? 0.0f
+                                     : sigma * (use_zbuf ? buffered_dist(zbuf, s, S, dnorm) : sample_dist(src, r, s, near, far, dnorm));
+                    const uint32_t tb = __float_as_uint(term);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(tb, tb, false, false);          // [1]: rows 1 1 3 3
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);          // [1]: rows 2 3 2 3
+                    const auto r48 = __builtin_amdgcn_permlane16_swap(r32[1], r32[1], false, false);  // [1]: rows 3 3 3 3
+                    if (g == 0u) {
+                        part += term;
+                        if (k0 + 1u < tiles) part += __uint_as_float(r16[1]);
+                        if (k0 + 2u < tiles) part += __uint_as_float(r32[1]);
+                        if (k0 + 3u < tiles) part += __uint_as_float(r48[1]);
+                    }
+                }
+            } else
             for (uint32_t k = 0; k < tiles; ++k) {
                 const uint32_t s = 16u * k + c;
                 const bool valid = s < S;
