@@ -343,10 +343,12 @@ def test_bf16_table_end_to_end():
     assert net.encoder.embeddings.grad.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("prec,S", [("f32", 192), ("f32", 50), ("bf16", 192), ("bf16", 37)])
+@pytest.mark.parametrize("prec,S", [("f32", 192), ("f32", 50), ("bf16", 192), ("bf16", 37), ("bf16", 17), ("bf16", 70), ("bf16", 100)])
 def test_per_sample_sigma_and_running_optical_depth(prec, S):
     """naf_render_forward_samples: sigma[r,s] and the wave-prefix-summed optical depth tau[r,s] = sum_{s' <= s} sigma * dist
-    against the oracle's per-sample network output and a float64 cumulative sum (render.py:192-201)."""
+    against the oracle's per-sample network output and a float64 cumulative sum (render.py:192-201).  The last assertion compares the
+    bf16 kernel's two tile loops bit for bit: with per-sample outputs it evaluates the activation per tile, without them once per four
+    tiles (lane group j keeps tile k0 + j) -- S = 17 / 37 / 70 / 100 / 192 are 2 / 3 / 5 / 7 / 12 tiles, every remainder mod 4."""
     from oracle import render_ref as R
     _abi, encoder, fused, network = _mods()
     net, ref = _naf_pair(seed=14)
