@@ -75,6 +75,55 @@ struct Mlp16Shared {
         if (threadIdx.x < 129u) bias[threadIdx.x] = bv;
         __syncthreads();
     }
+    // The same fragments through a staged copy of the three weight matrices.  build()'s loads are gathers straight from global memory
+    // -- 16 or 32 per lane, a different cache line per lane of a row group, the transposed fragments strided by a whole row -- and
+    // tools/mlp_stamps.py put them at 13 500 of the backward kernel's 52 900 cycles at the reference's batch (three workgroups per
+    // CU queue on the same address path).  Here the 4 096 weights arrive as 16 coalesced dwords per thread in ONE round trip, land in
+    // a padded LDS image (row pitch 33 / 65 floats: the rows of a fragment's 16 lanes fall into different banks) and the gathers run
+    // on the LDS.  Same values, same conversion: the fragments are bit-identical.  `stage`: kStageFloats floats of LDS that nothing
+    // else uses until the barrier at the end (the kernels lend the depth buffers / transpose images, which they fill later).
+    static constexpr uint32_t kStW0 = 0u, kStW1 = 32u * 33u, kStW2 = 2u * 32u * 33u, kStageFloats = 2u * 32u * 33u + 32u * 65u;
+    template <uint32_t kFrags>
+    static __device__ __forceinline__ void build_staged(unsigned char *lds, const float *__restrict__ mlp, float *stage) {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;          // blockDim.x == 256 (four waves)
+        const uint32_t r = lane & 15u, g = lane >> 4;
+        float w[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {                                        // u < 4: W0, u < 8: W1, else W2 (256 threads x 4 = a matrix of 1 024)
+            const uint32_t i = threadIdx.x + 256u * (u & 3u) + (u >= 8u ? 1024u * ((u - 8u) >> 2) : 0u);
+            w[u] = mlp[(u < 4u ? kW0 : u < 8u ? kW1 : kW2) + i];
+        }
+        float *bias = reinterpret_cast<float *>(lds + kBiasOff);
+        float bv = 0.0f;
+        if (threadIdx.x < 129u) {
+            const uint32_t k = threadIdx.x >> 5, j = threadIdx.x & 31u;
+            bv = mlp[k == 0 ? kB0 + j : k == 1 ? kB1 + j : k == 2 ? kB2 + j : k == 3 ? kW3 + j : kB3];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            const uint32_t i = threadIdx.x + 256u * (u & 3u) + (u >= 8u ? 1024u * ((u - 8u) >> 2) : 0u);
+            if (u < 8u) stage[(u < 4u ? kStW0 : kStW1) + (i >> 5) * 33u + (i & 31u)] = w[u];
+            else stage[kStW2 + (i >> 6) * 65u + (i & 63u)] = w[u];
+        }
+        if (threadIdx.x < 129u) bias[threadIdx.x] = bv;
+        __syncthreads();
+        constexpr uint32_t kIter = 2u * kFrags / 4u;
+#pragma unroll
+        for (uint32_t it = 0; it < kIter; ++it) {
+            const uint32_t fo = wave + 4u * it, f = fo >> 1, o = fo & 1u;
+            const uint32_t layer = f & 3u;                                         // 0: W0, 1: W1, 2: W2[:, :32], 3: W2[:, 32:]
+            const uint32_t base = layer == 0u ? kStW0 : layer == 1u ? kStW1 : layer == 2u ? kStW2 : kStW2 + 32u;
+            const uint32_t pitch = layer >= 2u ? 65u : 33u;
+            const bool transposed = f >= kFW0T;
+            const uint32_t sm = transposed ? 1u : pitch, sk = transposed ? pitch : 1u;
+            const uint32_t m = 16u * o + r;
+            bf16x8 pk;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) pk[j] = (__bf16)stage[base + m * sm + feat16(g, j) * sk];
+            reinterpret_cast<bf16x8 *>(lds + f * kFragBytes + o * kHalfBytes)[lane] = pk;
+        }
+        __syncthreads();
+    }
     static __device__ __forceinline__ bf16x8 frag(const unsigned char *lds, uint32_t f, uint32_t o, uint32_t lane) {
         return reinterpret_cast<const bf16x8 *>(lds + f * kFragBytes + o * kHalfBytes)[lane];
     }

@@ -234,7 +234,8 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
         float *zbuf = reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u)) + (threadIdx.x >> 6) * kMaxSamplesLds;
         Feat16Raw ahead;                                     // features of the next tile, in flight during this one
         if (wave < n_items) load_feat16(feat, B, wave * S + min(c, S - 1u), g, ahead);
-        Mlp16Shared::build<4>(smem, mlp);                    // after the first feature request: the two round trips overlap
+        // (after the first feature request: the two round trips overlap; the depth buffers are filled later: they stage the weights)
+        Mlp16Shared::build_staged<4>(smem, mlp, reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u)));
         Mlp16InRegs wt;
         wt.load(smem, lane);
         for (uint32_t r = wave; r < n_items; r += n_waves) {
@@ -304,7 +305,7 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
             if (lane == 0) out[r] = part;
         }
     } else {
-        Mlp16Shared::build<4>(smem, mlp);
+        Mlp16Shared::build_staged<4>(smem, mlp, reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u)));
         Mlp16InRegs wt;
         wt.load(smem, lane);
         const uint32_t tiles = (n_items + 15u) / 16u;
@@ -581,6 +582,14 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
                       const float *__restrict__ grad_acc, LossInputs loss, uint16_t *__restrict__ dfeat, float *__restrict__ slabs,
                       uint32_t n_rays, uint32_t B, int act, uint32_t parts, uint32_t *__restrict__ clear_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef NAF_MLP_STAMPS        // diagnostic builds (tools/mlp_stamps.py): shader-clock stamps of the kernel's phases, written behind the slab's payload
+    long long stamp_[6];
+    const long long wall0_ = wall_clock64();
+#define NAF_STAMP(i) stamp_[i] = clock64()
+#else
+#define NAF_STAMP(i)
+#endif
+    NAF_STAMP(0);
     if (clear_words != nullptr && blockIdx.x == 0u && threadIdx.x < kClearWords) clear_words[threadIdx.x] = 0u;      // see StepExtras
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = threadIdx.x >> 6;
     // wave-uniform values are made scalar explicitly: the ray record, its depths range and d acc then live in SGPRs
@@ -620,7 +629,8 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
     if (wave < n_items) load_feat16(feat, B, ray_of(wave) * S + min(16u * first_tile(wave - ray_of(wave) * parts) + c, S - 1u), g, ahead);
     // the weight fragments are built AFTER the first tile's features have been requested: the two round trips overlap (the build
     // ends with the workgroup barrier that makes the fragments visible)
-    Mlp16Shared::build<8>(smem, mlp);
+    Mlp16Shared::build_staged<8>(smem, mlp, reinterpret_cast<float *>(smem + kShAligned));      // (the transpose images and depth buffers lend the space)
+    NAF_STAMP(1);
     for (uint32_t item = wave; item < n_items; item += n_waves) {
         const uint32_t r = ray_of(item), part = item - r * parts, k_begin = first_tile(part), k_end = first_tile(part + 1u);
         const float *ray = src.rays + (size_t)r * 8;
@@ -737,6 +747,7 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         }
     }
 
+    NAF_STAMP(2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));     // non-negative floats order like uints
 
@@ -755,49 +766,95 @@ mlp16_backward_kernel(const uint16_t *__restrict__ feat, const float *__restrict
         db3 += __shfl_xor(db3, off, 64);
     }
     __syncthreads();                                                                // images / depth buffers are dead
-    float *red = reinterpret_cast<float *>(smem + kShAligned);
-    for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) red[i] = 0.0f;
-    __syncthreads();
-    for (uint32_t w = 0; w < 4u; ++w) {
-        if (wib == w) {
+    NAF_STAMP(3);
+    // ---- fold the 4 waves of the workgroup into one slab, in wave order: ((0 + a0) + a1) + a2) + a3 per entry, as ever --------------
+    // tools/mlp_stamps.py put the fold of rounds 2-4 -- the waves took turns adding their 64 + 17 values to one LDS image, `red[i] += x`,
+    // a dependent read-add-write round trip each -- at 14 000 of the kernel's 52 900 cycles at the reference's batch (with the pass
+    // that cleared the image); batching a turn's reads did not help (the turns stay dependent and three workgroups per CU take them at
+    // once), an XOR swizzle against the 4-way bank conflict of the lane groups neither.  Now nobody reads what it has just written: a wave
+    // STORES its values into an image of its own (no waits), and all 256 threads add two images entry by entry, coalesced.  There is
+    // room for two images -- A over the weight fragments, which are dead too, B over the transpose images -- so waves 0 and 1 write
+    // together and waves 2 and 3 follow one by one.  Same operands in the same order: the slab has the same bits.
+    float *imgA = reinterpret_cast<float *>(smem), *imgB = reinterpret_cast<float *>(smem + kShAligned);
+    static_assert(kShAligned >= (kSlabGmax + 1u) * 4u, "the fragment area holds one slab image");
+    auto put = [&](float *img) {
 #pragma unroll
-            for (uint32_t o = 0; o < 2; ++o)
+        for (uint32_t o = 0; o < 2; ++o)
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    const uint32_t out = 16u * o + 4u * g + i;
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t out = 16u * o + 4u * g + i;
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; ++q) {
-                        red[kW0 + out * 32u + 16u * q + c] += dW0[o][q][i];
-                        red[kW1 + out * 32u + 16u * q + c] += dW1[o][q][i];
-                    }
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) red[kW2 + out * 64u + 16u * q + c] += dW2[o][q][i];
+                for (uint32_t q = 0; q < 2; ++q) {
+                    img[kW0 + out * 32u + 16u * q + c] = dW0[o][q][i];
+                    img[kW1 + out * 32u + 16u * q + c] = dW1[o][q][i];
                 }
-            if (g == 0u) {
 #pragma unroll
-                for (uint32_t o = 0; o < 2; ++o) {
-                    red[kB0 + 16u * o + c] += db[0][o];
-                    red[kB1 + 16u * o + c] += db[1][o];
-                    red[kB2 + 16u * o + c] += db[2][o];
-                }
+                for (uint32_t q = 0; q < 4; ++q) img[kW2 + out * 64u + 16u * q + c] = dW2[o][q][i];
             }
-            if (c == 0u) {
+        if (g == 0u) {
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    red[kW3 + 4u * g + j] += dw3lo[j];
-                    red[kW3 + 16u + 4u * g + j] += dw3hi[j];
-                }
-            }
-            if (lane == 0u) {
-                red[kB3] += db3;
-                red[kSlabLoss] += loss_part;
-                red[kSlabGmax] = __uint_as_float(max(dmax, __float_as_uint(red[kSlabGmax])));      // +0.0f = bits 0 at the start
+            for (uint32_t o = 0; o < 2; ++o) {
+                img[kB0 + 16u * o + c] = db[0][o];
+                img[kB1 + 16u * o + c] = db[1][o];
+                img[kB2 + 16u * o + c] = db[2][o];
             }
         }
-        __syncthreads();
-    }
+        if (c == 0u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                img[kW3 + 4u * g + j] = dw3lo[j];
+                img[kW3 + 16u + 4u * g + j] = dw3hi[j];
+            }
+        }
+        if (lane == 0u) {
+            img[kB3] = db3;
+            img[kSlabLoss] = loss_part;
+            img[kSlabGmax] = __uint_as_float(dmax);
+        }
+    };
+    // A (+)= B, entry by entry; the first time A's entries are a wave's raw values and stand for 0 + a0 (the cleared image of old: -0.0
+    // becomes +0.0), the last time the sums go to the slab instead.  The maximum of the gradient bit patterns rides along.
+    auto combine = [&](bool first_pair, float *to_slab) {
+        constexpr uint32_t kPer = (kSlabGmax + 1u + 255u) / 256u;
+        float x[kPer], y[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = min(threadIdx.x + 256u * u, kSlabGmax);
+            x[u] = imgA[i];
+            y[u] = imgB[i];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = threadIdx.x + 256u * u;
+            if (i > kSlabGmax) break;
+            const float lhs = first_pair ? 0.0f + x[u] : x[u];
+            const float v = i == kSlabGmax ? __uint_as_float(max(__float_as_uint(x[u]), __float_as_uint(y[u]))) : lhs + y[u];
+            if (to_slab != nullptr) to_slab[i] = v; else imgA[i] = v;
+        }
+    };
     float *slab = slabs + (size_t)blockIdx.x * kSlabStride;
-    for (uint32_t i = threadIdx.x; i <= kSlabGmax; i += blockDim.x) slab[i] = red[i];
+    if (wib == 0u) put(imgA);
+    if (wib == 1u) put(imgB);
+    __syncthreads();
+    combine(true, nullptr);
+    __syncthreads();
+    if (wib == 2u) put(imgB);
+    __syncthreads();
+    combine(false, nullptr);
+    __syncthreads();
+    if (wib == 3u) put(imgB);
+    __syncthreads();
+    NAF_STAMP(4);
+    combine(false, slab);
+#ifdef NAF_MLP_STAMPS
+    NAF_STAMP(5);
+    if (threadIdx.x == 0u) {
+        uint32_t *dbg = reinterpret_cast<uint32_t *>(slab) + 4300u;
+        for (int i = 0; i < 6; ++i) dbg[i] = (uint32_t)(stamp_[i] - stamp_[0]);
+        dbg[6] = (uint32_t)wall0_; dbg[7] = (uint32_t)wall_clock64();
+    }
+#endif
+#undef NAF_STAMP
 }
 
 // ---- 5: slabs -> grad_mlp (+=), loss, gradient maximum: slab_reduce_block (mlp_slabs.h), as a launch of its own ----------------
@@ -911,7 +968,8 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
                            OutMap omap = OutMap{0u, 0u, 0u, 0u}) {
     if constexpr (std::is_same<P, PrecBF16>::value && C == 2) {
         {
-            const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + 4u * kMaxSamplesLds * 4u;
+            // (depth buffers of the four waves, which also stage the weights in the prologue: Mlp16Shared::build_staged)
+            const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + std::max<uint32_t>(4u * kMaxSamplesLds * 4u, Mlp16Shared::kStageFloats * 4u);
             const uint64_t waves16 = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves16 + 3) / 4, 256u * 8u));
             { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL((mlp16_forward_kernel<kRays>), dim3(grid16), dim3(256), lds16, s,
