@@ -210,7 +210,7 @@ typedef struct naf_render_cfg {
                                          need no workspace (naf_forward_workspace_bytes).  Bit-identical to the two-kernel path. */
 #define NAF_CFG_ENCODE_TWO_GATHERS 32u /* diagnostics: the encoder fetches the two x-neighbour corners of a cell with two gathers
                                          at every batch size instead of one 16-byte window (same results; A/B timing only) */
-#define NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD 128u /* diagnostics: the MLP backward splits rays into tile ranges only up to one wave per SIMD (rounds 1-2) instead of three */
+#define NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD 128u /* diagnostics: the MLP backward splits rays into tile ranges only up to one wave per SIMD (rounds 1-2) instead of three, and the bf16 MLP forward keeps one wave per ray at small batches (no mlp16_forward_split_kernel) */
 #define NAF_CFG_ENCODE_LEVEL_MAJOR 256u /* diagnostics: the encoder never splits the XCDs into groups (see NAF_CFG_ENCODE_GROUPS_*)       */
 #define NAF_CFG_ENCODE_WINDOWS 64u     /* diagnostics: the 16-byte window form at every batch size (default: below 600 000 points per
                                           call and for fp32 tables; two gathers with four points per lane in flight above)        */

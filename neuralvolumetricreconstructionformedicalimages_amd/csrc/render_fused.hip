@@ -321,6 +321,74 @@ mlp16_forward_kernel(const uint16_t *__restrict__ feat, const float *__restrict_
     }
 }
 
+// ---- 2b': the same line integrals with FOUR waves per ray (steps with fewer rays than two waves per SIMD: the reference's 1 024) ---
+// One wave per ray walks a ray's tiles one after the other, and with one wave per SIMD nothing hides the dependent MFMA / epilogue
+// chain of a tile: the forward of a 1 024-ray step is a single ray's latency (12 tiles, ~18 000 cycles) whatever the chip could do
+// beside it.  Here a workgroup takes a ray at a time and its four waves a quarter of the tiles each; the terms sigma * dist meet in
+// LDS and wave 0 adds them in tile order, then across the 16 lanes like mlp16_forward_kernel does: the same sums in the same order,
+// bit-identical line integrals.  Each wave fills the depths of its own tiles (+ 1) in its depth buffer; the term buffers (double-
+// buffered: one barrier per ray) live in the upper halves of the first two depth buffers, which is why S <= kMaxSamplesLds / 2.
+__global__ void __launch_bounds__(256, 4)
+mlp16_forward_split_kernel(const uint16_t *__restrict__ feat, const float *__restrict__ mlp, SrcRays src, float *__restrict__ out,
+                           uint32_t n_rays, uint32_t B, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, g = lane >> 4, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t S = src.S, tiles = (S + 15u) / 16u;
+    const uint32_t k_begin = wib * tiles / 4u, k_end = (wib + 1u) * tiles / 4u;
+    float *zall = reinterpret_cast<float *>(smem + ((Mlp16Shared::kBytes + 15u) & ~15u));
+    float *zbuf = zall + wib * kMaxSamplesLds;
+    float *terms[2] = {zall + kMaxSamplesLds / 2u, zall + kMaxSamplesLds + kMaxSamplesLds / 2u};
+    Act16 a;
+    Feat16Raw ahead;
+    if (blockIdx.x < n_rays) load_feat16(feat, B, blockIdx.x * S + min(16u * k_begin + c, S - 1u), g, ahead);
+    Mlp16Shared::build_staged<4>(smem, mlp, zall);
+    Mlp16InRegs wt;
+    wt.load(smem, lane);
+    uint32_t turn = 0u;
+    for (uint32_t r = blockIdx.x; r < n_rays; r += gridDim.x, turn ^= 1u) {
+        const float *ray = src.rays + (size_t)r * 8;
+        const float near = ray[6], far = ray[7];
+        const float dnorm = sqrtf(ray[3] * ray[3] + ray[4] * ray[4] + ray[5] * ray[5]);
+        for (uint32_t s = 16u * k_begin + lane; s < min(S, 16u * k_end + 1u); s += 64u) zbuf[s] = src.depth(r, s, near, far);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float *T = terms[turn];
+        for (uint32_t k0 = k_begin; k0 < k_end; k0 += 4u) {
+            float zsel = 0.0f;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t k = k0 + j;
+                if (k >= k_end) break;                                   // uniform
+                const Feat16Raw now = ahead;
+                {   // next tile of this wave's range, else the first one of the workgroup's next ray, else (nothing left) this tile again
+                    const bool more = k + 1u < k_end;
+                    const uint32_t rn = more ? r : (r + gridDim.x < n_rays ? r + gridDim.x : r);
+                    const uint32_t sn = 16u * (more ? k + 1u : k_begin) + c;
+                    load_feat16(feat, B, rn * S + min(sn, S - 1u), g, ahead);
+                }
+                const float z4 = mlp16_tile_forward(wt, feat16_operand(now), a);
+                zsel = g == j ? z4 : zsel;
+            }
+            const uint32_t s = 16u * (k0 + g) + c;
+            const float sigma = last_act16(act, zsel);
+            const float term = s >= S ? 0.0f : sigma * buffered_dist(zbuf, s, S, dnorm);
+            if (k0 + g < k_end) T[s] = term;
+        }
+        __syncthreads();
+        if (wib == 0u) {
+            float part = 0.0f;
+            if (g == 0u)
+                for (uint32_t k = 0; k < tiles; ++k) part += T[16u * k + c];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);     // the 16 points of lane group 0
+            if (lane == 0) out[r] = part;
+        }
+        // (no second barrier: the next ray's terms go to the other buffer, and this buffer is written again only behind the next
+        // ray's barrier, which wave 0 reaches after it has read it)
+    }
+}
+
 // ---- 2c: gathers + MLP + line integral in one kernel, features in registers (fused_forward.h; forward-only calls) -----------
 // Src = SrcRays: one wave per ray (out[r] = sum_s sigma * dist, optional per-sample outputs).  Any other source: a plain point
 // list / generated grid, out[omap.at(p)] = sigma(p).  `feat` != nullptr additionally stores the features (diagnostic:
@@ -970,6 +1038,20 @@ static int run_mlp_forward(const void *feat, const float *mlp, const SrcRays &sr
         {
             // (depth buffers of the four waves, which also stage the weights in the prologue: Mlp16Shared::build_staged)
             const uint32_t lds16 = ((Mlp16Shared::kBytes + 15u) & ~15u) + std::max<uint32_t>(4u * kMaxSamplesLds * 4u, Mlp16Shared::kStageFloats * 4u);
+            if constexpr (kRays) {
+                // fewer rays than two waves per SIMD, line integrals only: four waves a ray (mlp16_forward_split_kernel)
+                const uint32_t tiles = (src.S + 15u) / 16u;
+                if (sigma_out == nullptr && depth_out == nullptr && n_items < 2048u && src.S <= kMaxSamplesLds / 2u && tiles >= 4u &&
+                    (cfg->flags & NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD) == 0u) {
+                    ProfScope prof_("mlp_forward_kernel", s);
+#ifndef NAF_FWD_SPLIT_GRID
+#define NAF_FWD_SPLIT_GRID 1024u      // workgroups at most (four fit a CU); A/B builds override it
+#endif
+                    hipLaunchKernelGGL(mlp16_forward_split_kernel, dim3(std::max(1u, std::min(n_items, NAF_FWD_SPLIT_GRID))), dim3(256), lds16, s,
+                                       (const uint16_t *)feat, mlp, src, out, n_items, B, cfg->last_activation);
+                    return check_launch("mlp16_forward_split_kernel");
+                }
+            }
             const uint64_t waves16 = kRays ? n_items : ((uint64_t)n_items + 15) / 16;
             const uint32_t grid16 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((waves16 + 3) / 4, 256u * 8u));
             { ProfScope prof_("mlp_forward_kernel", s); hipLaunchKernelGGL((mlp16_forward_kernel<kRays>), dim3(grid16), dim3(256), lds16, s,
