@@ -1587,6 +1587,12 @@ static int levels_scatter_impl(const float *rays, const float *t_rand, const voi
 
 using namespace naf;
 
+#ifdef NAF_REDUCE_STAMPS
+extern "C" int naf_debug_reduce_stamps(uint32_t *host, uint32_t n_words) {      // diagnostic builds only (tools/reduce_stamps.py)
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(naf::g_reduce_stamps), (size_t)std::min<uint32_t>(n_words, 2048u * 8u) * 4u) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int naf_scatter_overflow_count(const naf_render_cfg *cfg, uint64_t n_points, const void *workspace, uint32_t *count_host) {
     if (!cfg || !workspace || !count_host) return fail(NAF_ERR_INVALID_ARGUMENT, "scatter_overflow_count: null pointer");
     const Workspace w = carve(const_cast<void *>(workspace), cfg, n_points);

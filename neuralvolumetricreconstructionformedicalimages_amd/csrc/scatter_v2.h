@@ -477,12 +477,24 @@ __device__ __forceinline__ PairFx load_record(const PairFx *p) {
 #endif
 }
 
+#ifdef NAF_REDUCE_STAMPS        // diagnostic builds (tools/reduce_stamps.py): shader-clock stamps of pass 2's phases, eight words per workgroup
+__device__ uint32_t g_reduce_stamps[2048 * 8];
+#define NAF_RSTAMP(i) rs_[i] = clock64()
+#else
+#define NAF_RSTAMP(i)
+#endif
+
 template <bool kAdam, bool kFast>
 __global__ void __launch_bounds__(1024)
 scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__restrict__ runs, const int32_t *__restrict__ offsets,
                        float *__restrict__ grad_table, const uint32_t *__restrict__ gmax_bits, uint32_t level_base, uint32_t ly_begin,
                        uint32_t H, BinPlan plan, AdamTail adam) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef NAF_REDUCE_STAMPS
+    long long rs_[5] = {0, 0, 0, 0, 0};
+    const long long rwall_ = wall_clock64();
+#endif
+    NAF_RSTAMP(0);
     const uint32_t bucket = blockIdx.x, ly = ly_begin + blockIdx.y, level = level_base + ly;      // ly: level slot of the bin pass
     const LevelMeta lm = make_level_meta<3>(offsets, level, H);
     const uint32_t off = lm.offset, T = lm.size;
@@ -499,7 +511,13 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
     unsigned long long *acc0 = reinterpret_cast<unsigned long long *>(smem), *acc1 = acc0 + pitch;
 
     struct __attribute__((packed, aligned(4))) Quad { float x, y, z, w; };              // level offsets may be odd: 8-byte aligned only
-    constexpr uint32_t kPreQ = kAdam ? 4u : 0u;                  // quads (two rows x two channels) prefetched per thread
+#ifndef NAF_RED_PREQ
+#define NAF_RED_PREQ 2u          // Two of a thread's four quads at T = 2^19: tools/reduce_stamps.py shows the workgroup's loads returning at
+#endif                           // the rate the memory system delivers them, in order -- with all four quads (196 KB) requested in front, the
+                                 // records queue behind them and the record phase starts at 18 000 of the workgroup's 43 000 cycles.  Same-box
+                                 // A/B, 1 / 2 / 3 / 4 quads: 0.092 / 0.090 / 0.090-0.091 / 0.092-0.093 ms at 1 024 rays, flat at 65 536
+                                 // (profiles/round4_ab_reducer_adam_prefetch_depth.jsonl; A/B builds override the macro).
+    constexpr uint32_t kPreQ = kAdam ? NAF_RED_PREQ : 0u;       // quads (two rows x two channels) prefetched per thread
     Quad preq_p[kPreQ ? kPreQ : 1u], preq_m[kPreQ ? kPreQ : 1u], preq_v[kPreQ ? kPreQ : 1u];
     // quad q = local rows 2q, 2q + 1 = two CONSECUTIVE table rows when chunks hold at least two rows (s >= 1) and both exist
     const uint32_t n_quads = (rows_local + 1u) >> 1;
@@ -533,6 +551,7 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
         for (uint32_t i = threadIdx.x; i < pitch; i += T_) a2[i] = u64x2{0ull, 0ull};      // pitch * 2 cells of 8 bytes
     }
     __syncthreads();
+    NAF_RSTAMP(1);
 
     auto add = [&](const PairFx &r) {
         const uint32_t la = r.head & ((1u << kFxLocalBits) - 1u);
@@ -625,7 +644,9 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
             }
         }
     }
+    NAF_RSTAMP(2);
     __syncthreads();
+    NAF_RSTAMP(3);
 
     float *__restrict__ gg = grad_table + (size_t)off * 2u;
     const float nan = __builtin_nanf("");
@@ -750,6 +771,15 @@ scatter_reduce2_kernel(const PairFx *__restrict__ blocks, const uint32_t *__rest
             }
         }
     }
+#ifdef NAF_REDUCE_STAMPS
+    NAF_RSTAMP(4);
+    if (threadIdx.x == 0u) {
+        uint32_t *dbg = g_reduce_stamps + ((blockIdx.y * gridDim.x + blockIdx.x) & 2047u) * 8u;
+        for (int i = 0; i < 5; ++i) dbg[i] = (uint32_t)(rs_[i] - rs_[0]);
+        dbg[5] = (uint32_t)rwall_; dbg[6] = (uint32_t)wall_clock64(); dbg[7] = level;
+    }
+#endif
 }
+#undef NAF_RSTAMP
 
 }  // namespace naf
