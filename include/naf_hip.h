@@ -226,6 +226,9 @@ typedef struct naf_render_cfg {
 #define NAF_CFG_MIN_BUCKETS_MASK (3u << NAF_CFG_MIN_BUCKETS_SHIFT)
 #define NAF_CFG_SCATTER_PAIR12 2048u     /* diagnostics: the binned scatter of the canonical shape (two bf16 channels) keeps the 12-byte pair
                                             records and the kernels of rounds 2-3 (scatter_binned.h) instead of scatter_v2.h's 8-byte ones */
+#define NAF_CFG_LEVELS_GATHER_PASS 32768u /* diagnostics: naf_levels_scatter re-orders the gradient blocks into [level][point][C] with a pass of
+                                            its own (rounds 3-4) even where pass 1 of the scatter can read them in place (two bf16
+                                            channels) -- same results bit for bit; A/B timing and tests                              */
 #define NAF_CFG_TEST_TINY_BLOCKS 4096u   /* tests: the record blocks of pass 1 hold a quarter of a tile's records, so that most
                                             records take the overflow route (counted global atomics) and the reducer's Adam tail has
                                             spilled contributions to fold in                                                        */
@@ -407,7 +410,9 @@ int naf_levels_field_step(const float *rays, const float *t_rand, const float *t
  * naf_render_workspace_bytes(cfg, B).  grad_embeddings (+=) receives the gradient of the owned levels' rows -- unless `adam` is
  * given and the reducer can apply the update itself (as in naf_render_train_adam; *adam_applied = 1): then the rows of the owned
  * levels in adam->param / exp_avg / exp_avg_sq / param_lp are stepped and grad_embeddings stays zero.  With *adam_applied = 0
- * the caller steps those rows with naf_adam_step.  adam->mlp_* are ignored (the MLP is replicated: its gradient is all-reduced). */
+ * the caller steps those rows with naf_adam_step.  adam->mlp_* are ignored (the MLP is replicated: its gradient is all-reduced).
+ * With two bf16 channels (the canonical shape) the blocks are read in place by pass 1 of the scatter -- they must stay untouched until
+ * the call's kernels have run; other shapes copy them into the workspace first (NAF_CFG_LEVELS_GATHER_PASS: always). */
 int naf_levels_scatter(const float *rays, const float *t_rand, const void *grad_blocks, size_t block_stride_bytes, uint32_t n_ranks,
                        const int32_t *offsets, float *grad_embeddings, uint32_t n_rays, const naf_render_cfg *cfg,
                        uint32_t level_begin, uint32_t level_end, void *workspace, const naf_table_adam *adam, int *adam_applied,

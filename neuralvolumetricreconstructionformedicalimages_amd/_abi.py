@@ -30,6 +30,7 @@ CFG_ENCODE_GROUPS_2 = 512
 CFG_ENCODE_GROUPS_4 = 1024
 CFG_SCATTER_PAIR12 = 2048
 CFG_TEST_TINY_BLOCKS = 4096
+CFG_LEVELS_GATHER_PASS = 32768
 CFG_MIN_BUCKETS_SHIFT = 13          # bits 13-14: at least 64 << value row buckets per level in the binned scatter
 GRAD_INPUTS_NONE, GRAD_INPUTS_EXACT, GRAD_INPUTS_REFERENCE = 0, 1, 2
 

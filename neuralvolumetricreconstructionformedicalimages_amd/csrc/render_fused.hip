@@ -1006,7 +1006,7 @@ static int check_cfg(const naf_render_cfg *cfg, const char *who) {
     if (cfg->table_dtype < NAF_F32 || cfg->table_dtype > NAF_BF16) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad table_dtype");
     if (cfg->last_activation < 0 || cfg->last_activation > 3) return fail(NAF_ERR_UNSUPPORTED, "fused field: bad last_activation");
     if (!(cfg->bound > 0.0f)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: bound must be > 0");
-    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
+    if (cfg->flags & ~(NAF_CFG_PER_LEVEL_LAUNCHES | NAF_CFG_EXPLICIT_DEPTHS | NAF_CFG_LEVELS_INTERLEAVED | NAF_CFG_FORWARD_FUSED | NAF_CFG_FUSED_STORE_FEATURES | NAF_CFG_ENCODE_TWO_GATHERS | NAF_CFG_ENCODE_WINDOWS | NAF_CFG_BACKWARD_ONE_WAVE_PER_SIMD | NAF_CFG_ENCODE_LEVEL_MAJOR | NAF_CFG_TEST_TINY_BLOCKS | NAF_CFG_ENCODE_GROUPS_2 | NAF_CFG_ENCODE_GROUPS_4 | NAF_CFG_MIN_BUCKETS_MASK | NAF_CFG_SCATTER_PAIR12 | NAF_CFG_LEVELS_GATHER_PASS)) return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: unknown cfg flag");
     if (cfg->scatter_mode < NAF_SCATTER_AUTO || cfg->scatter_mode > NAF_SCATTER_BINNED)
         return fail(NAF_ERR_INVALID_ARGUMENT, "fused field: scatter_mode must be NAF_SCATTER_AUTO, _ATOMIC or _BINNED");
     (void)who;
@@ -1211,7 +1211,7 @@ static int run_binned_scatter(const SrcRays &src, const void *dfeat, const int32
 static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end,
                                const naf_grad_buckets *buckets, hipStream_t s, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
-                               DrawJob *next_draw = nullptr) {
+                               DrawJob *next_draw = nullptr, const GradBlocks *from_blocks = nullptr) {
 #ifndef NAF_V2_LV_FEW
 #define NAF_V2_LV_FEW 4u      // levels per bin workgroup when tiles are scarce.  A/B builds (tools/build_variant.sh) override it: 2 gains 2 us at
                               // 512 rays and loses 9 at 4 096, 8 the other way round (profiles/round4_ab_reducer_nt_loads_and_levels_per_bin_workgroup.jsonl)
@@ -1228,6 +1228,11 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
     auto bin = big ? (many ? scatter_bin2_kernel<2u * NT, kLvMany, 0u> : scatter_bin2_kernel<2u * NT, kLvFew, 0u>)
                    : nb64 ? (many ? scatter_bin2_kernel<NT, kLvMany, 6u> : scatter_bin2_kernel<NT, kLvFew, 6u>)
                           : (many ? scatter_bin2_kernel<NT, kLvMany, 0u> : scatter_bin2_kernel<NT, kLvFew, 0u>);
+    if (from_blocks != nullptr)      // level-parallel: `dfeat` = the all-to-all's blocks, read in place (scatter_v2.h, GradBlocks)
+        bin = big ? (many ? scatter_bin2_kernel<2u * NT, kLvMany, 0u, true> : scatter_bin2_kernel<2u * NT, kLvFew, 0u, true>)
+                  : nb64 ? (many ? scatter_bin2_kernel<NT, kLvMany, 6u, true> : scatter_bin2_kernel<NT, kLvFew, 6u, true>)
+                         : (many ? scatter_bin2_kernel<NT, kLvMany, 0u, true> : scatter_bin2_kernel<NT, kLvFew, 0u, true>);
+    const GradBlocks gb = from_blocks != nullptr ? *from_blocks : GradBlocks{};
     const bool fast = adam != nullptr && adam->lp != nullptr;        // tables with a 16-bit shadow: adam_math.h
     auto red = adam == nullptr ? scatter_reduce2_kernel<false, false> : fast ? scatter_reduce2_kernel<true, true> : scatter_reduce2_kernel<true, false>;
     const AdamTail tail = adam != nullptr ? *adam : AdamTail{};
@@ -1248,7 +1253,7 @@ static int run_binned_scatter2(const SrcRays &src, const void *dfeat, const int3
         if (next_draw != nullptr && next_draw->count != 0u) { dj = *next_draw; next_draw->count = 0u; }      // consumed
         const uint32_t spare = (job.slabs != nullptr ? kSlabReduceBlocks : 0u) + (dj.count + threads - 1u) / threads;
         hipLaunchKernelGGL(bin, dim3(plan.n_tiles + spare, (nl + LV - 1u) / LV), dim3(threads), bin_lds, s, src, (const uint16_t *)dfeat,
-                           offsets, grad_table, (PairFx *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job, dj);
+                           offsets, grad_table, (PairFx *)w.regions, w.counts, w.overflow, B, cfg->H, l0, nl, plan, job, dj, gb);
         job = SlabReduce{};
         return check_launch("scatter_bin_kernel");
     };
@@ -1282,10 +1287,11 @@ template <typename P, uint32_t C>
 static int run_hash_backward_levels(const SrcRays &src, const void *dfeat, const int32_t *offsets, float *grad_table, uint32_t B,
                                     const naf_render_cfg *cfg, const Workspace &w, uint32_t lv_begin, uint32_t lv_end, hipStream_t s,
                                     const naf_grad_buckets *buckets = nullptr, const AdamTail *adam = nullptr, const SlabReduce *slab_job = nullptr,
-                                    DrawJob *next_draw = nullptr) {
+                                    DrawJob *next_draw = nullptr, const GradBlocks *from_blocks = nullptr) {
     using FT = typename P::feat_t;
+    if (from_blocks != nullptr && !(w.binned && scatter_v2(cfg))) return fail(NAF_ERR_LAUNCH, "hash backward: only the 8-byte-record scatter reads gradient blocks in place");
     if (w.binned) {
-        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job, next_draw);
+        if (scatter_v2(cfg)) return run_binned_scatter2(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job, next_draw, from_blocks);
         if (cfg->mlp_precision == NAF_F32) return run_binned_scatter<P, C, PairF32<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
         return run_binned_scatter<P, C, PairBF16<C>>(src, dfeat, offsets, grad_table, B, cfg, w, lv_begin, lv_end, buckets, s, adam, slab_job);
     }
@@ -1547,6 +1553,21 @@ static int levels_scatter_impl(const float *rays, const float *t_rand, const voi
     if (w.binned) {
         if (hipMemsetAsync(w.overflow, 0, 34 * sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");      // counters + maximum
     } else if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), s) != hipSuccess) return fail(NAF_ERR_LAUNCH, "levels_scatter: memset failed");
+    AdamTail tail;
+    const bool fuse = adam != nullptr && adam_tail_possible_levels(cfg, w, lv_begin, lv_end);
+    if (fuse) { tail = *adam; tail.overflow = w.overflow; }
+    if (adam_applied != nullptr) *adam_applied = fuse ? 1 : 0;
+    // The canonical shape (two bf16 channels, 8-byte records) reads the blocks in place: pass 1 finds a point's gradient inside its
+    // rank's block and takes the maximum on its way (scatter_v2.h, GradBlocks).  Other shapes, the fp32 parity mode and
+    // NAF_CFG_LEVELS_GATHER_PASS keep the pass below.
+    if constexpr (sizeof(T) == 2u && C == 2u) {
+        const bool in_place = w.binned && scatter_v2(cfg) && (cfg->flags & NAF_CFG_LEVELS_GATHER_PASS) == 0u && block_stride % 4u == 0u &&
+                              ((uintptr_t)blocks & 3u) == 0u && (uint64_t)n_ranks * (block_stride / 4u) < (1ull << 32) && B / n_ranks >= 2u;
+        if (in_place) {
+            const GradBlocks gb = make_grad_blocks(B / n_ranks, (uint32_t)(block_stride / 4u), lv_begin, gmax);
+            return run_hash_backward_levels<P, C>(src, blocks, offsets, grad_emb, B, cfg, w, lv_begin, lv_end, s, nullptr, fuse ? &tail : nullptr, nullptr, nullptr, &gb);
+        }
+    }
     const bool vec = (run * sizeof(T)) % 16u == 0u && block_stride % 16u == 0u && ((uintptr_t)blocks & 15u) == 0u && ((uintptr_t)w.dfeat & 15u) == 0u;
     if ((uint64_t)n_ranks * nl > 65535u) return fail(NAF_ERR_INVALID_ARGUMENT, "levels_scatter: too many (rank, level) blocks");
     const uint32_t units = vec ? run / (uint32_t)(16u / sizeof(T)) : run;
@@ -1558,10 +1579,6 @@ static int levels_scatter_impl(const float *rays, const float *t_rand, const voi
         else hipLaunchKernelGGL((levels_gather_kernel<T, false>), dim3(gx, n_ranks * nl), dim3(256), 0, s, (const unsigned char *)blocks, block_stride, (T *)w.dfeat, n_ranks, nl, run, lv_begin, gmax);
     }
     if (int rc = check_launch("levels_gather_kernel")) return rc;
-    AdamTail tail;
-    const bool fuse = adam != nullptr && adam_tail_possible_levels(cfg, w, lv_begin, lv_end);
-    if (fuse) { tail = *adam; tail.overflow = w.overflow; }
-    if (adam_applied != nullptr) *adam_applied = fuse ? 1 : 0;
     return run_hash_backward_levels<P, C>(src, w.dfeat, offsets, grad_emb, B, cfg, w, lv_begin, lv_end, s, nullptr, fuse ? &tail : nullptr, nullptr);
 }
 

@@ -89,6 +89,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
     return v;
 }
 
+// wave-wide maximum the same way; the result is valid in lane 63
+__device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
 // LDS: hist[2][NB] | start[NB] | misc (4 dwords) | staging[slots + 1] records | side list [3/8 slots] x 12 bytes.
 // One workgroup = one tile of NT x 2 points x LV levels.  Per level: (A) every thread builds the records of its points in registers;
@@ -102,11 +113,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
 // 57 % of the time and issued as many scalar as vector instructions -- exec-mask juggling around per-record conditions.  So the
 // common level (not merged, every lane emits: lanes past the end of the batch carry a zero gradient and their records add nothing)
 // has a body of its own without a single per-lane branch; a record that finds its block full is noticed by ONE vote per level.
-template <uint32_t NT, uint32_t LV, uint32_t kLog2NB>            // kLog2NB: 6 = the 64-bucket plan, 0 = as the plan says (T >= 2^20)
+// kFromBlocks (level-parallel steps, naf_levels_scatter): the feature gradients still lie as the all-to-all delivered them -- one block per
+// source rank, [rank][owned level][that rank's points][2] -- and pass 1 reads them in place instead of behind a pass that re-orders them
+// (levels_gather_kernel: 0.014 of a rank's 0.233 ms per step at 8 ranks).  The step's maximum |gradient|, which the fixed-point reducer
+// scales by and which a single-GPU step gets from its MLP backward, is taken on the way: every gradient of the owned levels passes
+// through exactly one lane here.
+struct GradBlocks {
+    uint32_t rank_points;          // points of one rank (B / n_ranks), >= 2
+    uint32_t block_points;         // distance between two ranks' blocks, in points (4 bytes each)
+    uint32_t level0;               // first owned level: (level l, point b of rank r) sits at r * block_points + (l - level0) * rank_points + b
+    uint32_t magic, shift;         // b / rank_points = mulhi(b, magic) >> shift for b < 2^31 (make_grad_blocks)
+    uint32_t *gmax_bits;           // bit pattern of max |gradient| (zeroed by the host before the launch)
+};
+// magic = ceil(2^(31 + l) / d), l = ceil(log2 d): exact quotients for every numerator below 2^31 (Granlund & Montgomery with one bit
+// to spare, so the multiplier fits 32 bits); d >= 2.
+static inline GradBlocks make_grad_blocks(uint32_t rank_points, uint32_t block_points, uint32_t level0, uint32_t *gmax_bits) {
+    uint32_t l = 0;
+    while ((1ull << l) < rank_points) ++l;
+    const uint64_t two = 1ull << (31u + l);
+    return GradBlocks{rank_points, block_points, level0, (uint32_t)((two + rank_points - 1u) / rank_points), l - 1u, gmax_bits};
+}
+
+template <uint32_t NT, uint32_t LV, uint32_t kLog2NB, bool kFromBlocks = false>      // kLog2NB: 6 = the 64-bucket plan, 0 = as the plan says (T >= 2^20)
 __global__ void __launch_bounds__(NT, 4)                       // 512 threads: two workgroups per CU; 1024: one -- 16 waves either way
 scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_t *__restrict__ offsets, float *__restrict__ grad_table,
                     PairFx *__restrict__ blocks, uint32_t *__restrict__ runs, uint32_t *__restrict__ overflow, uint32_t B, uint32_t H,
-                    uint32_t level_base, uint32_t n_levels, BinPlan plan, SlabReduce slab_job, DrawJob draw_job) {
+                    uint32_t level_base, uint32_t n_levels, BinPlan plan, SlabReduce slab_job, DrawJob draw_job, GradBlocks gb = GradBlocks{}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= plan.n_tiles) {
         // spare workgroups behind the tiles: the MLP backward's slab reduction (scatter_binned.h), then -- naf_render_train_adam_draw --
@@ -136,6 +168,10 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
     const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < 2u * NB; i += NT) hist[i] = 0u;
     if (threadIdx.x < 4u) misc[threadIdx.x] = 0u;
+    // kFromBlocks: misc[3] = the largest |gradient| the workgroup knows of, at first what earlier workgroups of the step have published
+    // (an agent-scope load: a plain one is served by this XCD's L2, which keeps the zero it saw first whatever the memory-side atomics
+    // of other workgroups have done since)
+    if constexpr (kFromBlocks) { if (threadIdx.x == 3u) misc[3] = __hip_atomic_load(gb.gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     float x[PTS][3];
     uint32_t bp[PTS];
@@ -148,12 +184,27 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         src.get(bp[q], x[q]);
     }
     const float spacing = src.sample_spacing();
+    // where (level, point) sits: [level][B][2], or inside its rank's block (bp[] then holds the point's offset for level0)
+    if constexpr (kFromBlocks) {
+#pragma unroll
+        for (uint32_t q = 0; q < PTS; ++q) {
+            const uint32_t r = __umulhi(bp[q], gb.magic) >> gb.shift;          // bp / rank_points
+            bp[q] += r * (gb.block_points - gb.rank_points);
+        }
+    }
+    auto grad_at = [&](uint32_t level, uint32_t q) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (kFromBlocks) return *reinterpret_cast<const uint32_t *>(grad + ((size_t)(level - gb.level0) * gb.rank_points + bp[q]) * 2u);
+        else return *reinterpret_cast<const uint32_t *>(grad + ((size_t)level * B + bp[q]) * 2u);
+    };
     uint32_t graw[PTS];                                            // this level's feature gradients (2 x bf16), requested one level ahead
+    uint32_t wmax = 0u;                                            // kFromBlocks: largest |gradient| this wave has seen (fp32 bit pattern, wave-uniform)
     if (blockIdx.y * LV < n_levels) {
 #pragma unroll
-        for (uint32_t q = 0; q < PTS; ++q) graw[q] = *reinterpret_cast<const uint32_t *>(grad + ((size_t)(level_base + blockIdx.y * LV) * B + bp[q]) * 2u);
+        for (uint32_t q = 0; q < PTS; ++q) graw[q] = grad_at(level_base + blockIdx.y * LV, q);
     }
     __syncthreads();
+    if constexpr (kFromBlocks) wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[3]);
+    const uint32_t seed = wmax;                                    // what was published when the workgroup started (wave-uniform)
     uint32_t n_overflow = 0, n_overflow_level = 0;
 
     for (uint32_t it = 0; it < LV; ++it) {
@@ -169,6 +220,23 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         const bool merging = m.scale * spacing < 0.5f && m.scale < 65535.0f;
         const bool fast = !merging && bucket_shift(m.size, 0u) <= map.hs;             // not merged, one chunk per bucket: row >> hs == 0
 
+#ifndef NAF_DIAG_BLOCKS_NO_MAX
+        if constexpr (kFromBlocks) {
+            // largest |gradient| of the level in this wave, as an fp32 bit pattern (NaN > Inf > finite: a non-finite gradient poisons the
+            // step as it does on one GPU; a lane past the end of the batch holds the last point's gradient, a value of the batch).  Per
+            // level and through LDS rather than in a register across the level bodies: the 128-register variants have none to spare.
+            // The wave keeps the largest value it knows of in a scalar register (at first the workgroup's word) and does nothing while no
+            // lane exceeds it -- gradients of one step are of one magnitude, so a wave mostly pays three vector instructions per point
+            // and a vote.
+            uint32_t gm = 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < PTS; ++q) gm = max(gm, max((graw[q] << 16) & 0x7fffffffu, graw[q] & 0x7fff0000u));
+            if (__ballot(gm > wmax) != 0ull) {
+                wmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_to_lane63(gm), 63);
+                if (lane == 0u) atomicMax(&misc[3], wmax);
+            }
+        }
+#endif
         uint32_t head[PTS][4], pay[PTS][4], bkt[PTS][4], rank[PTS][4];
         bool on[PTS];
         // a second corner that travels as a record of its own: counted and ranked like every record, kept in the side list
@@ -324,11 +392,26 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         // retires in order: a wait placed behind the stores would sit out their round trip -- scatter_binned.h)
         if (it + 1u < LV && ly + 1u < n_levels) {
 #pragma unroll
-            for (uint32_t q = 0; q < PTS; ++q) graw[q] = *reinterpret_cast<const uint32_t *>(grad + ((size_t)(level + 1u) * B + bp[q]) * 2u);
+            for (uint32_t q = 0; q < PTS; ++q) graw[q] = grad_at(level + 1u, q);
         }
         lds_barrier();
 #pragma unroll
         for (uint32_t q = 0; q < PTS; ++q) asm volatile("" : "+v"(graw[q]) : : "memory");      // pin the wait here
+#ifndef NAF_DIAG_BLOCKS_NO_TAIL
+        if constexpr (kFromBlocks) {
+            // The workgroup publishes its maximum ONCE, behind the first barrier of its last level (every wave has looked at every level by
+            // then), and only if it beats what the workgroup found published at its start.  Same-address atomics retire ~12 ns apart and a
+            // wave's slot is not released before its atomic is acknowledged; here the rest of the level hides part of that.  Measured on
+            // one box, us per launch on top of a build that takes no maximum at all (50.5 / 41.5 us at 8 / 4 ranks x 1 024 rays,
+            // profiles/round4_ab_levels_in_place_maximum_variants.jsonl): here +2 / +5.5; at the very end of the workgroup +6 / +9, behind a
+            // fresh look at the global word there +3.5 / +7; an atomic per raise of the workgroup's word +8.5 / +27.  The per-level part above
+            // costs 0.7.  No memory wait follows in this wave: nothing is prefetched any more.
+            if ((it + 1u == LV || ly + 1u == n_levels) && threadIdx.x == 0u) {
+                const uint32_t m = misc[3];
+                if (m > seed) atomicMax(gb.gmax_bits, m);
+            }
+        }
+#endif
 
         // ---- B: counters -> exclusive offsets, run words, total ---------------------------------------------------------------------
         // (the counters and the side-list length of the OTHER parity are what the next level uses: nobody reads them any more -- their

@@ -31,8 +31,9 @@ def _batch(n, S, seed=11):
     return rays.cuda(), (torch.rand(n, generator=g) * 0.3).cuda(), (torch.rand(n, generator=g) > 0.2).cuda()
 
 
-def _levels_step(eng, N, rays, target, weight):
-    """One optimisation step of `eng` (a single-process NAFEngine used as a bag of buffers) the level-parallel way."""
+def _levels_step(eng, N, rays, target, weight, pad=0):
+    """One optimisation step of `eng` (a single-process NAFEngine used as a bag of buffers) the level-parallel way.  `pad`: elements
+    of NaN between the gradient blocks of two ranks (block_stride_bytes larger than a block)."""
     from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused
     lib, sp = _abi.lib(), _abi.stream_ptr()
     enc = eng.net.encoder
@@ -74,9 +75,10 @@ def _levels_step(eng, N, rays, target, weight):
     offs = eng.offsets.tolist()
     fused_tail = []
     for k in range(N):                                            # "all-to-all" back: owner k receives its levels' gradients from every rank
-        blocks = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0).contiguous()      # [N, per * run]
+        blocks = torch.full((N, per * run + pad), float("nan"), dtype=fdt, device=eng.device)
+        blocks[:, :per * run] = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0)      # [N, per * run (+ pad)]
         applied = ctypes.c_int(-1)
-        _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), per * run * esz, N, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g),
+        _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), (per * run + pad) * esz, N, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g),
                                           n_all, ctypes.byref(cfg_all), k * per, (k + 1) * per, _abi.ptr(ws), ctypes.byref(st),
                                           ctypes.byref(applied), sp), "levels_scatter")
         fused_tail.append(applied.value)
@@ -118,6 +120,65 @@ def test_level_parallel_entry_points_equal_the_single_gpu_step(N, table, n_rays,
     assert np.mean(np.abs(m1 - m2) > (1e-5 if table == "fp32" else 2e-2) * float(np.abs(m2).max()) + 1e-9) < 1e-2
     if lev.emb_lp is not None:
         assert torch.equal(lev.emb_lp, lev.emb.to(lev.table_dtype))                 # the shadow follows the master on every owned row
+
+
+@pytest.mark.parametrize("N,n_rays,S,buckets,pad,log2T", [
+    (2, 256, 64, 0, 0, 14), (4, 512, 64, 1, 6, 14), (8, 512, 64, 2, 2, 14), (16, 400, 48, 2, 10, 14),
+    (4, 200, 50, 0, 2, 14),                                               # 10 000 points: the last tile is ragged, ranks end inside tiles
+    (2, 8192, 192, 0, 0, 19), (8, 8192, 192, 2, 4, 19)])                  # 1.5 M points: the all-levels-per-workgroup variants of pass 1
+def test_scatter_reads_the_gradient_blocks_in_place_bit_for_bit(N, n_rays, S, buckets, pad, log2T):
+    """Two bf16 channels: pass 1 of the scatter finds a point's gradient inside its source rank's block and takes the step's maximum
+    |gradient| itself (scatter_v2.h, GradBlocks); NAF_CFG_LEVELS_GATHER_PASS keeps the separate re-ordering pass of rounds 3-4.
+    Same records, same fixed-point scale: table, moments and shadow are equal bit for bit after two steps.  (Every case here has
+    unsplit reducer launches: split ones add their partial sums with fp32 atomics in no fixed order, whichever way the gradients were read;
+    test_level_parallel_entry_points_equal_the_single_gpu_step covers them through the in-place route against the single-GPU step.)"""
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    a = NAFEngine(_make(log2T=log2T), S, perturb=True, lr=1e-2, table_dtype=torch.bfloat16, seed=5)
+    b = NAFEngine(_make(log2T=log2T), S, perturb=True, lr=1e-2, table_dtype=torch.bfloat16, seed=5)
+    a._levels_flags = buckets << _abi.CFG_MIN_BUCKETS_SHIFT
+    b._levels_flags = (buckets << _abi.CFG_MIN_BUCKETS_SHIFT) | _abi.CFG_LEVELS_GATHER_PASS
+    rays, target, mask = _batch(n_rays, S)
+    weight = mask.float() / mask.float().sum()
+    start = a.emb.clone()
+    for step in range(2):
+        _, tail_a = _levels_step(a, N, rays, target, weight, pad=pad)
+        _, tail_b = _levels_step(b, N, rays, target, weight, pad=0)
+        assert tail_a == tail_b
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.emb).all()
+    assert float((a.emb - start).abs().max()) > 0.0                      # the table moved
+    for name in ("emb", "emb_m", "emb_v", "emb_lp", "mlp"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_a_non_finite_gradient_poisons_the_in_place_scatter_as_it_does_the_gather_pass():
+    """The maximum travels as a bit pattern (NaN > Inf > finite), so one Inf among the gradient blocks reaches the fixed-point scale."""
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    S, n_rays, N = 64, 256, 4
+    out = []
+    for flag in (0, _abi.CFG_LEVELS_GATHER_PASS):
+        eng = NAFEngine(_make(), S, perturb=True, lr=1e-2, table_dtype=torch.bfloat16, seed=5)
+        eng._levels_flags = flag
+        rays, _, _ = _batch(n_rays, S)
+        enc = eng.net.encoder
+        L, C = enc.num_levels, enc.level_dim
+        per, run = L // N, n_rays // N * S * C
+        cfg_all = eng._cfg(0)
+        ws = fused.workspace(cfg_all, n_rays * S, eng.device)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        blocks = (torch.randn(N, per * run, device="cuda", generator=g) * 1e-3).to(torch.bfloat16)
+        blocks[2, run + 77] = float("inf")
+        _abi.check(_abi.lib().naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), per * run * 2, N, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g),
+                                                 n_rays, ctypes.byref(cfg_all), per, 2 * per, _abi.ptr(ws), None, None, _abi.stream_ptr()), "levels_scatter")
+        torch.cuda.synchronize()
+        out.append(eng.emb_g.clone())
+    offs = eng.offsets.tolist()
+    owned = out[0].reshape(-1)[offs[per] * C:offs[2 * per] * C]
+    assert not torch.isfinite(owned).all()
+    assert torch.equal(torch.isfinite(out[0]), torch.isfinite(out[1]))
+    assert torch.equal(torch.nan_to_num(out[0], nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(out[1], nan=7.0, posinf=8.0, neginf=9.0))
 
 
 def test_level_parallel_first_step_gradient_matches_the_plain_backward_fp32():

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--samples", type=int, default=192)
     ap.add_argument("--table", choices=["fp32", "bf16", "fp16"], default=None, help="table storage (default: what --precision implies)")
     ap.add_argument("--default-buckets", action="store_true", help="keep the 64 row buckets per level of the single-GPU step (split reducer launches below 4 levels per rank)")
+    ap.add_argument("--gather-pass", action="store_true", help="NAF_CFG_LEVELS_GATHER_PASS: re-order the gradient blocks with a pass of its own (rounds 3-4) instead of reading them in place")
     args = ap.parse_args()
     dev = torch.device("cuda")
     N, n = args.ranks, args.rays
@@ -122,11 +123,13 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(7)
     if not args.default_buckets:
         lev._levels_flags = {1: 2, 2: 2}.get(16 // N, 0) << _abi.CFG_MIN_BUCKETS_SHIFT      # what engine._init_level_parallel sets
+    if args.gather_pass:
+        lev._levels_flags |= _abi.CFG_LEVELS_GATHER_PASS
     ref_step_ms = []
     rays, target = torch.empty(N * n, 8, device=dev), torch.empty(N * n, device=dev)
     weight = torch.full((N * n,), 1.0 / (N * n), device=dev)
     prof = {}
-    timers, report = {}, {"ranks": N, "rays_per_rank": n, "precision": args.precision, "log2T": args.log2T, "samples": args.samples, "table": args.table, "row_buckets": "64" if args.default_buckets else "engine default", "steps": []}
+    timers, report = {}, {"ranks": N, "rays_per_rank": n, "precision": args.precision, "log2T": args.log2T, "samples": args.samples, "table": args.table, "row_buckets": "64" if args.default_buckets else "engine default", "gradient_blocks": "gather pass" if args.gather_pass else "read in place", "steps": []}
     for step in range(args.steps):
         if chest:
             scan.sampler.draw_ranks(step, n, N, rays, target)
