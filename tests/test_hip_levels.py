@@ -31,40 +31,48 @@ def _batch(n, S, seed=11):
     return rays.cuda(), (torch.rand(n, generator=g) * 0.3).cuda(), (torch.rand(n, generator=g) > 0.2).cuda()
 
 
-def _levels_step(eng, N, rays, target, weight, pad=0):
+def _levels_step(eng, N, rays, target, weight, pad=0, halves=1):
     """One optimisation step of `eng` (a single-process NAFEngine used as a bag of buffers) the level-parallel way.  `pad`: elements
-    of NaN between the gradient blocks of two ranks (block_stride_bytes larger than a block)."""
+    of NaN between the gradient blocks of two ranks (block_stride_bytes larger than a block).  `halves` = 2: the split form -- every
+    rank's rays in two halves that travel separately (one half's all-to-all can then sit behind the other half's kernels); the batch is
+    read as [half 0 of rank 0 .. N-1 | half 1 of rank 0 .. N-1], each half is encoded and rendered on its own, and ONE scatter call takes
+    the 2 N returned blocks as those of 2 N ranks -- no entry point knows about halves."""
     from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused
     lib, sp = _abi.lib(), _abi.stream_ptr()
     enc = eng.net.encoder
     L, C, S = enc.num_levels, enc.level_dim, eng.n_samples
     n_all = rays.shape[0]
-    n, per = n_all // N, L // N
-    run = n * S * C
+    n_half = n_all // halves                                      # rays of one half, all ranks
+    n, per = n_half // N, L // N
+    run = n * S * C                                               # elements of one (rank, half, level)
     fdt = torch.float32 if int(eng.mlp_precision) == _abi.F32 else torch.bfloat16
     esz = 4 if fdt == torch.float32 else 2
     cfg_all = eng._cfg(0)
     ws = fused.workspace(cfg_all, n_all * S, eng.device)
-    feats = []
-    for k in range(N):                                            # every owner encodes its levels for all points
-        out = torch.full((N, per, run), float("nan"), dtype=fdt, device=eng.device)      # one block per destination rank
-        _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_all, N,
-                                         ctypes.byref(cfg_all), k * per, (k + 1) * per, sp), "levels_encode")
-        feats.append(out)
     eng.loss.zero_()
     part = torch.zeros(1, device=eng.device)
     acc = torch.empty(n_all, device=eng.device)
-    grads = []
-    for r in range(N):                                            # "all-to-all": rank r receives every owner's levels of its points
-        feat = torch.cat([f[r] for f in feats], 0).contiguous()                  # [L, run]
-        dfeat = torch.full((L, run), float("nan"), dtype=fdt, device=eng.device)
-        cfg = eng._cfg(r * n)
-        sl = slice(r * n, (r + 1) * n)
-        _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl].contiguous()), None, _abi.ptr(target[sl].contiguous()), _abi.ptr(weight[sl].contiguous()),
-                                             _abi.ptr(feat), _abi.ptr(eng.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(eng.mlp_g),
-                                             _abi.ptr(part), n, ctypes.byref(cfg), _abi.ptr(ws), None, sp), "levels_field_step")
-        eng.loss.add_(part)                                       # (the all-reduce of the real step)
-        grads.append(dfeat)
+    grads = []                                                    # [half * N + rank] -> [L, run]
+    for h in range(halves):
+        base = h * n_half
+        rays_h = rays[base:base + n_half].contiguous()
+        cfg_h = eng._cfg(base)
+        feats = []
+        for k in range(N):                                        # every owner encodes its levels for all points of the half
+            out = torch.full((N, per, run), float("nan"), dtype=fdt, device=eng.device)      # one block per destination rank
+            _abi.check(lib.naf_levels_encode(_abi.ptr(rays_h), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_half, N,
+                                             ctypes.byref(cfg_h), k * per, (k + 1) * per, sp), "levels_encode")
+            feats.append(out)
+        for r in range(N):                                        # "all-to-all": rank r receives every owner's levels of its points
+            feat = torch.cat([f[r] for f in feats], 0).contiguous()                  # [L, run]
+            dfeat = torch.full((L, run), float("nan"), dtype=fdt, device=eng.device)
+            cfg = eng._cfg(base + r * n)
+            sl = slice(base + r * n, base + (r + 1) * n)
+            _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl].contiguous()), None, _abi.ptr(target[sl].contiguous()), _abi.ptr(weight[sl].contiguous()),
+                                                 _abi.ptr(feat), _abi.ptr(eng.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(eng.mlp_g),
+                                                 _abi.ptr(part), n, ctypes.byref(cfg), _abi.ptr(ws), None, sp), "levels_field_step")
+            eng.loss.add_(part)                                   # (the all-reduce of the real step)
+            grads.append(dfeat)
     eng.step_count += 1
     st = _abi.TableAdam()
     st.param, st.exp_avg, st.exp_avg_sq = eng.emb.data_ptr(), eng.emb_m.data_ptr(), eng.emb_v.data_ptr()
@@ -74,11 +82,12 @@ def _levels_step(eng, N, rays, target, weight, pad=0):
     st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = eng.emb.numel(), eng.lr, b1, b2, eng.eps, eng.step_count, 1.0
     offs = eng.offsets.tolist()
     fused_tail = []
-    for k in range(N):                                            # "all-to-all" back: owner k receives its levels' gradients from every rank
-        blocks = torch.full((N, per * run + pad), float("nan"), dtype=fdt, device=eng.device)
-        blocks[:, :per * run] = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0)      # [N, per * run (+ pad)]
+    V = halves * N                                                # blocks the owner receives
+    for k in range(N):                                            # "all-to-all" back: owner k receives its levels' gradients from every rank (and half)
+        blocks = torch.full((V, per * run + pad), float("nan"), dtype=fdt, device=eng.device)
+        blocks[:, :per * run] = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0)      # [V, per * run (+ pad)]
         applied = ctypes.c_int(-1)
-        _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), (per * run + pad) * esz, N, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g),
+        _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), (per * run + pad) * esz, V, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g),
                                           n_all, ctypes.byref(cfg_all), k * per, (k + 1) * per, _abi.ptr(ws), ctypes.byref(st),
                                           ctypes.byref(applied), sp), "levels_scatter")
         fused_tail.append(applied.value)
@@ -120,6 +129,36 @@ def test_level_parallel_entry_points_equal_the_single_gpu_step(N, table, n_rays,
     assert np.mean(np.abs(m1 - m2) > (1e-5 if table == "fp32" else 2e-2) * float(np.abs(m2).max()) + 1e-9) < 1e-2
     if lev.emb_lp is not None:
         assert torch.equal(lev.emb_lp, lev.emb.to(lev.table_dtype))                 # the shadow follows the master on every owned row
+
+
+@pytest.mark.parametrize("N,table,n_rays,S,buckets", [(2, "bf16", 256, 64, 0), (4, "bf16", 512, 64, 1), (8, "bf16", 512, 64, 2), (8, "fp32", 256, 48, 2),
+                                                       (4, "fp32", 200, 50, 0)])
+def test_level_parallel_step_in_two_halves_equals_the_single_gpu_step(N, table, n_rays, S, buckets):
+    """The split form: each rank's rays travel as two halves -- two encodes, two MLP passes, ONE scatter over 2 N
+    blocks.  Counter-based jitter, so the sample depths depend on where a ray sits in the batch: the reference is the single-GPU step
+    on the batch in the order the halves imply, which is the order given."""
+    from neuralvolumetricreconstructionformedicalimages_amd import _abi
+    from neuralvolumetricreconstructionformedicalimages_amd.engine import NAFEngine
+    dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[table]
+    ref = NAFEngine(_make(), S, perturb=True, lr=1e-2, table_dtype=dtype, seed=5)
+    lev = NAFEngine(_make(), S, perturb=True, lr=1e-2, table_dtype=dtype, seed=5)
+    lev._levels_flags = buckets << _abi.CFG_MIN_BUCKETS_SHIFT
+    rays, target, mask = _batch(n_rays, S)
+    weight = mask.float() / mask.float().sum()
+    for step in range(2):
+        ref.train_step(rays, target, weight)
+        acc, _ = _levels_step(lev, N, rays, target, weight, halves=2)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(acc.cpu().numpy(), ref.acc[:n_rays].cpu().numpy(), rtol=2e-6 if table == "fp32" else 2e-2, atol=1e-6)
+        np.testing.assert_allclose(float(lev.loss.item()), float(ref.loss.item()), rtol=1e-4 if table == "fp32" else 1e-2)
+        assert float(lev.emb_g.abs().max()) == 0.0
+    a, b = lev.emb.cpu().numpy(), ref.emb.cpu().numpy()
+    assert np.mean(np.abs(a - b) > 2e-3) < 1e-3
+    np.testing.assert_allclose(lev.mlp.cpu().numpy(), ref.mlp.cpu().numpy(), rtol=0, atol=2e-4 if table == "fp32" else 2e-3)
+    m1, m2 = lev.emb_m.cpu().numpy(), ref.emb_m.cpu().numpy()
+    assert np.mean(np.abs(m1 - m2) > (1e-5 if table == "fp32" else 2e-2) * float(np.abs(m2).max()) + 1e-9) < 1e-2
+    if lev.emb_lp is not None:
+        assert torch.equal(lev.emb_lp, lev.emb.to(lev.table_dtype))
 
 
 @pytest.mark.parametrize("N,n_rays,S,buckets,pad,log2T", [

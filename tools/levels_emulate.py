@@ -21,12 +21,16 @@ import bench  # noqa: E402
 from neuralvolumetricreconstructionformedicalimages_amd import _abi, fused  # noqa: E402
 
 
-def levels_step(eng, N, rays, target, weight, timers=None):
+def levels_step(eng, N, rays, target, weight, timers=None, halves=1):
+    """`halves` = 2: the split form -- the batch is read as [half 0 of rank 0 .. N-1 | half 1 of rank 0 .. N-1]; each half is encoded and
+    rendered on its own (so that one half's all-to-all could sit behind the other half's kernels) and ONE scatter call takes the 2 N
+    returned blocks as those of 2 N ranks."""
     lib, sp = _abi.lib(), _abi.stream_ptr()
     enc = eng.net.encoder
     L, C, S = enc.num_levels, enc.level_dim, eng.n_samples
     n_all = rays.shape[0]
-    n, per = n_all // N, L // N
+    n_half = n_all // halves
+    n, per = n_half // N, L // N
     run = n * S * C
     fdt = torch.float32 if int(eng.mlp_precision) == _abi.F32 else torch.bfloat16
     esz = 4 if fdt == torch.float32 else 2
@@ -43,26 +47,30 @@ def levels_step(eng, N, rays, target, weight, timers=None):
         timers.setdefault(name, []).append((a, b))
         return out
 
-    feats = []
-    for k in range(N):
-        out = torch.empty(N, per, run, dtype=fdt, device=eng.device)
-        timed("encode", lambda: _abi.check(lib.naf_levels_encode(_abi.ptr(rays), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_all, N,
-                                                                  ctypes.byref(cfg_all), k * per, (k + 1) * per, sp), "levels_encode"))
-        feats.append(out)
     eng.loss.zero_()
     part = torch.zeros(1, device=eng.device)
     acc = torch.empty(n_all, device=eng.device)
     grads = []
-    for r in range(N):
-        feat = torch.cat([f[r] for f in feats], 0).contiguous()
-        dfeat = torch.empty(L, run, dtype=fdt, device=eng.device)
-        cfg = eng._cfg(r * n)
-        sl = slice(r * n, (r + 1) * n)
-        timed("field", lambda: _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl]), None, _abi.ptr(target[sl]), _abi.ptr(weight[sl]), _abi.ptr(feat),
-                                                                     _abi.ptr(eng.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(eng.mlp_g), _abi.ptr(part), n,
-                                                                     ctypes.byref(cfg), _abi.ptr(ws), None, sp), "levels_field_step"))
-        eng.loss.add_(part)
-        grads.append(dfeat)
+    for h in range(halves):
+        base = h * n_half
+        rays_h = rays[base:base + n_half]
+        cfg_h = eng._cfg(base)
+        feats = []
+        for k in range(N):
+            out = torch.empty(N, per, run, dtype=fdt, device=eng.device)
+            timed("encode", lambda: _abi.check(lib.naf_levels_encode(_abi.ptr(rays_h), None, _abi.ptr(eng.table), _abi.ptr(eng.offsets), _abi.ptr(out), n_half, N,
+                                                                      ctypes.byref(cfg_h), k * per, (k + 1) * per, sp), "levels_encode"))
+            feats.append(out)
+        for r in range(N):
+            feat = torch.cat([f[r] for f in feats], 0).contiguous()
+            dfeat = torch.empty(L, run, dtype=fdt, device=eng.device)
+            cfg = eng._cfg(base + r * n)
+            sl = slice(base + r * n, base + (r + 1) * n)
+            timed("field", lambda: _abi.check(lib.naf_levels_field_step(_abi.ptr(rays[sl]), None, _abi.ptr(target[sl]), _abi.ptr(weight[sl]), _abi.ptr(feat),
+                                                                         _abi.ptr(eng.mlp), _abi.ptr(acc[sl]), _abi.ptr(dfeat), _abi.ptr(eng.mlp_g), _abi.ptr(part), n,
+                                                                         ctypes.byref(cfg), _abi.ptr(ws), None, sp), "levels_field_step"))
+            eng.loss.add_(part)
+            grads.append(dfeat)
     eng.step_count += 1
     st = _abi.TableAdam()
     st.param, st.exp_avg, st.exp_avg_sq = eng.emb.data_ptr(), eng.emb_m.data_ptr(), eng.emb_v.data_ptr()
@@ -72,12 +80,13 @@ def levels_step(eng, N, rays, target, weight, timers=None):
     st.n, st.lr, st.beta1, st.beta2, st.eps, st.step, st.grad_scale = eng.emb.numel(), eng.lr, b1, b2, eng.eps, eng.step_count, 1.0
     offs = eng.offsets.tolist()
     fused_tail = []
+    V = halves * N
     for k in range(N):
         blocks = torch.stack([g[k * per:(k + 1) * per].reshape(-1) for g in grads], 0).contiguous()
         applied = ctypes.c_int(-1)
 
         def scatter():
-            _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), per * run * esz, N, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g), n_all,
+            _abi.check(lib.naf_levels_scatter(_abi.ptr(rays), None, _abi.ptr(blocks), per * run * esz, V, _abi.ptr(eng.offsets), _abi.ptr(eng.emb_g), n_all,
                                               ctypes.byref(cfg_all), k * per, (k + 1) * per, _abi.ptr(ws), ctypes.byref(st), ctypes.byref(applied), sp),
                        "levels_scatter")
             if not applied.value:
@@ -98,6 +107,7 @@ def main():
     ap.add_argument("--samples", type=int, default=192)
     ap.add_argument("--table", choices=["fp32", "bf16", "fp16"], default=None, help="table storage (default: what --precision implies)")
     ap.add_argument("--default-buckets", action="store_true", help="keep the 64 row buckets per level of the single-GPU step (split reducer launches below 4 levels per rank)")
+    ap.add_argument("--split", action="store_true", help="the split form: every rank's rays in two halves (two encodes, two MLP passes, one scatter over 2 N blocks)")
     ap.add_argument("--gather-pass", action="store_true", help="NAF_CFG_LEVELS_GATHER_PASS: re-order the gradient blocks with a pass of its own (rounds 3-4) instead of reading them in place")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -129,7 +139,7 @@ def main():
     rays, target = torch.empty(N * n, 8, device=dev), torch.empty(N * n, device=dev)
     weight = torch.full((N * n,), 1.0 / (N * n), device=dev)
     prof = {}
-    timers, report = {}, {"ranks": N, "rays_per_rank": n, "precision": args.precision, "log2T": args.log2T, "samples": args.samples, "table": args.table, "row_buckets": "64" if args.default_buckets else "engine default", "gradient_blocks": "gather pass" if args.gather_pass else "read in place", "steps": []}
+    timers, report = {}, {"ranks": N, "rays_per_rank": n, "precision": args.precision, "log2T": args.log2T, "samples": args.samples, "table": args.table, "row_buckets": "64" if args.default_buckets else "engine default", "gradient_blocks": "gather pass" if args.gather_pass else "read in place", "rays_in_halves": bool(args.split), "steps": []}
     for step in range(args.steps):
         if chest:
             scan.sampler.draw_ranks(step, n, N, rays, target)
@@ -146,7 +156,7 @@ def main():
         torch.cuda.synchronize()
         ref_step_ms.append(e0.elapsed_time(e1))
         _abi.profile_enable(step > 0)
-        acc, fused_tail = levels_step(lev, N, rays, target, weight, timers if step > 0 else None)
+        acc, fused_tail = levels_step(lev, N, rays, target, weight, timers if step > 0 else None, halves=2 if args.split else 1)
         torch.cuda.synchronize()
         if step > 0:
             for k, (c, ms) in _abi.profile_collect().items():
