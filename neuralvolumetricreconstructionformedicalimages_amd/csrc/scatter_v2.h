@@ -171,7 +171,10 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
     // kFromBlocks: misc[3] = the largest |gradient| the workgroup knows of, at first what earlier workgroups of the step have published
     // (an agent-scope load: a plain one is served by this XCD's L2, which keeps the zero it saw first whatever the memory-side atomics
     // of other workgroups have done since)
-    if constexpr (kFromBlocks) { if (threadIdx.x == 3u) misc[3] = __hip_atomic_load(gb.gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    uint32_t published = 0u;                                       // (lane 3 of wave 0 keeps its copy: see `seed` below)
+    if constexpr (kFromBlocks) {
+        if (threadIdx.x == 3u) { published = __hip_atomic_load(gb.gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[3] = published; }
+    }
 
     float x[PTS][3];
     uint32_t bp[PTS];
@@ -203,8 +206,11 @@ scatter_bin2_kernel(SrcRays src, const uint16_t *__restrict__ grad, const int32_
         for (uint32_t q = 0; q < PTS; ++q) graw[q] = grad_at(level_base + blockIdx.y * LV, q);
     }
     __syncthreads();
+    // wmax may start from misc[3] even if a faster wave has raised the word already (whatever is in the word is accounted for);
+    // `seed`, against which thread 0 decides whether the workgroup has anything to publish, may not -- it comes from the register of
+    // the lane that loaded the published value (wave 0; the other waves never use theirs)
     if constexpr (kFromBlocks) wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[3]);
-    const uint32_t seed = wmax;                                    // what was published when the workgroup started (wave-uniform)
+    const uint32_t seed = (uint32_t)__builtin_amdgcn_readlane((int)published, 3);
     uint32_t n_overflow = 0, n_overflow_level = 0;
 
     for (uint32_t it = 0; it < LV; ++it) {
